@@ -1,0 +1,309 @@
+/* mcbs.h — C ABI of the MI355X-native batched CyberBattleSim step engine (libmcbs.so).
+ *
+ * Drop-in boundary for ONE hot path of zsh239040/MARLon: the attacker/defender environment
+ * step behind `cyberbattle._env.cyberbattle_env.CyberBattleEnv.step` as driven by
+ * `marlon.simulate` and marlon's env wrappers.  The reference is pure Python (no FFI of its
+ * own); every entry point below names the reference interface it replaces.  Conventions:
+ *   - plain pointers and sizes only, no torch / C++ types;
+ *   - return 0 on success, a negative MCBS_E* code otherwise; mcbs_last_error() gives the
+ *     thread-local message;
+ *   - the library owns the environment state (HBM), the caller owns every I/O buffer
+ *     (device pointers, e.g. torch-ROCm `tensor.data_ptr()`);
+ *   - every call is asynchronous on the caller's stream (`void* stream` is a hipStream_t,
+ *     NULL = the null stream) and performs no hidden synchronisation unless stated;
+ *   - one batch handle is not re-entrant; different handles are independent (one per GPU).
+ *
+ * The same topology blob is read by the CPU oracle (oracle/cbs_oracle.c), which is test
+ * infrastructure and never linked into this library.
+ */
+#ifndef MCBS_H
+#define MCBS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCBS_ABI_VERSION 1u
+
+/* ---- error codes ---- */
+#define MCBS_OK           0
+#define MCBS_EINVAL      -1   /* bad argument / malformed blob */
+#define MCBS_ELIMIT      -2   /* topology exceeds an engine limit (see MCBS_MAX_*) */
+#define MCBS_EHIP        -3   /* HIP runtime error (message has hipGetErrorString) */
+#define MCBS_ENOMEM      -4
+#define MCBS_ESTATE      -5   /* call not valid in the current state */
+
+/* ---- engine limits ---- */
+#define MCBS_MAX_NODES        256   /* node ids are u8; masks are <= 4 x u64 */
+#define MCBS_MAX_PORTS         32   /* firewall / listen tables are u32 port masks */
+#define MCBS_MAX_PROPS         64   /* property sets are u64 masks */
+#define MCBS_MAX_SLOTS         32   /* vulnerabilities applicable to one node (library + own) */
+#define MCBS_MAX_LOCAL_VULNS   32   /* local-vulnerability mask per node is u32 */
+#define MCBS_MAX_CRED_STRINGS 1024
+#define MCBS_MAX_TRIPLES      4096  /* distinct (node, port, credential) triples */
+
+/* ================================================================================
+ * Topology blob ("MCBT", little endian, every section 16-byte aligned).
+ * Built on the host by marlon_amd.flatten from a model.Environment
+ * (reference records: simulation/model.py:63-77,226-247,263-345,347-362,377-396).
+ * ================================================================================ */
+#define MCBS_TOPO_MAGIC 0x5442434Du /* "MCBT" */
+
+/* outcome kinds (reference classes, simulation/model.py:118-198) */
+enum {
+    MCBS_OUT_NONE = 0,
+    MCBS_OUT_LEAKED_CREDENTIALS = 1,
+    MCBS_OUT_LEAKED_NODES = 2,
+    MCBS_OUT_PRIVILEGE_ESCALATION = 3,
+    MCBS_OUT_LATERAL_MOVE = 4,
+    MCBS_OUT_CUSTOMER_DATA = 5,
+    MCBS_OUT_PROBE_SUCCEEDED = 6,
+    MCBS_OUT_PROBE_FAILED = 7,
+    MCBS_OUT_EXPLOIT_FAILED = 8,
+    MCBS_OUT_OTHER = 9
+};
+
+/* precondition byte code (oracle only; the GPU uses mcbs_vuln_slot.precond_tt) */
+enum {
+    MCBS_OP_PROP_BASE = 0x00, /* 0x00..0x3F push static property bit i */
+    MCBS_OP_TAG_BASE = 0x40,  /* 0x40..0x43 push tag privilege_k */
+    MCBS_OP_TRUE = 0x80,
+    MCBS_OP_FALSE = 0x81,
+    MCBS_OP_NOT = 0x82,
+    MCBS_OP_AND = 0x83,
+    MCBS_OP_OR = 0x84
+};
+
+#define MCBS_NODE_INSTALLED0 0x01u /* agent_installed in the initial environment */
+#define MCBS_NODE_REIMAGABLE 0x02u
+
+typedef struct mcbs_topo_header { /* 192 bytes */
+    uint32_t magic, abi_version, total_bytes, header_bytes;
+    uint32_t n_nodes, n_ports, n_props, n_local, n_remote;
+    uint32_t n_cred_strings, n_triples, max_slots;
+    uint32_t n_slots_total, n_payload, n_services, n_allowed, n_code;
+    uint32_t max_leak_per_action; /* longest LeakedCredentials list (env.py:421-428) */
+    uint32_t avail_any_order;     /* 1: every availability term is an exact multiple of one power of two,
+                                     so the node-order sum of actions.py:728-745 is order independent */
+    uint32_t reserved0;
+    double   total_sla_weight;    /* sum of node sla weights, node order */
+    double   full_availability;   /* availability with every node Running (node-order sum / total) */
+    uint32_t off_node;            /* mcbs_node_static[n_nodes] */
+    uint32_t off_slot_of;         /* uint8[n_nodes * (n_local + n_remote)], 0xFF = not present */
+    uint32_t off_slot;            /* mcbs_vuln_slot[n_nodes * max_slots] */
+    uint32_t off_payload;         /* mcbs_payload[n_payload] */
+    uint32_t off_service;         /* mcbs_service[n_services] */
+    uint32_t off_allowed;         /* uint16[n_allowed] credential-string ids */
+    uint32_t off_triple;          /* mcbs_triple[n_triples] */
+    uint32_t off_code;            /* uint8[n_code] precondition byte code */
+    uint32_t off_init_order;      /* uint8[n_nodes]: nodes owned at reset, network order, then 0xFF */
+    uint32_t n_init_owned;
+    uint32_t reserved[14];
+} mcbs_topo_header;
+
+typedef struct mcbs_node_static { /* 64 bytes */
+    uint64_t props;        /* static properties that are declared identifiers (bit = index) */
+    double   sla_weight;
+    double   avail_term;   /* sla_weight * (1 + running service weights) / (1 + all service weights) */
+    int32_t  value;
+    uint32_t fw_in_allow;  /* port bit set iff the FIRST incoming rule for the port is ALLOW */
+    uint32_t fw_out_allow;
+    uint32_t listen;       /* port bit set iff some service has that name (running or not) */
+    uint32_t local_mask;   /* bit l set iff local vuln id l is in the library or in the node's dict (env.py:658-663) */
+    uint16_t svc_off, svc_cnt;
+    uint8_t  flags;        /* MCBS_NODE_* */
+    uint8_t  priv0;        /* initial privilege level */
+    uint8_t  tags0;        /* privilege_k tags literally present in the initial property list */
+    uint8_t  n_slots;
+    uint32_t pad[3];
+} mcbs_node_static;
+
+typedef struct mcbs_vuln_slot { /* 32 bytes; slot s of node n applies to target n */
+    double   cost;
+    uint64_t probe_mask;   /* ProbeSucceeded: declared, non-tag properties it reveals */
+    uint32_t payload_off;
+    uint16_t payload_cnt;
+    uint16_t precond_tt;   /* bit t = precondition value on this node when its tag set is t (4 bits) */
+    uint32_t code_off;     /* oracle byte code */
+    uint16_t code_len;
+    uint8_t  kind;         /* MCBS_OUT_* */
+    uint8_t  level;        /* PrivilegeEscalation level */
+} mcbs_vuln_slot;
+
+typedef struct mcbs_payload { /* 8 bytes: one LeakedCredentials / LeakedNodesId list entry */
+    uint16_t node;
+    uint16_t cred;         /* credential-string id (LeakedCredentials) */
+    uint16_t triple;       /* (node, port, credential) triple id (LeakedCredentials) */
+    uint16_t port;
+} mcbs_payload;
+
+typedef struct mcbs_service { /* 16 bytes */
+    double   sla_weight;
+    uint16_t allowed_off, allowed_cnt;
+    uint8_t  port, running;
+    uint16_t pad;
+} mcbs_service;
+
+typedef struct mcbs_triple { /* 8 bytes */
+    uint16_t node, cred;
+    uint16_t port, pad;
+} mcbs_triple;
+
+/* ================================================================================
+ * Batch configuration = CyberBattleEnv constructor arguments (env.py:470-485) plus the
+ * in-env defender (defender.py:27-55) and batching knobs.
+ * ================================================================================ */
+#define MCBS_DEFENDER_NONE 0
+#define MCBS_DEFENDER_SCAN_AND_REIMAGE 1 /* ScanAndReimageCompromisedMachines */
+
+#define MCBS_RNG_PHILOX 0 /* draws = Philox4x32-10(key=(seed, global env id), ctr=(step, pair#, episode, 0)) */
+#define MCBS_RNG_TAPE   1 /* draws read from a caller tape (parity against the reference's global RNGs) */
+
+typedef struct mcbs_batch_cfg {
+    uint32_t abi_version;
+    uint32_t n_envs;
+    int32_t  device;                 /* HIP device ordinal */
+    uint32_t maximum_node_count;     /* bounds (env.py:172-224) */
+    uint32_t maximum_total_credentials;
+    uint32_t maximum_discoverable_credentials_per_action;
+    /* AttackerGoal (env.py:227-241); has_attacker_goal = 0 means attacker_goal=None */
+    uint32_t has_attacker_goal;
+    uint32_t goal_own_atleast;
+    double   goal_reward;
+    double   goal_low_availability;
+    double   goal_own_atleast_percent;
+    /* DefenderGoal / DefenderConstraint (env.py:244-254) */
+    uint32_t defender_goal_eviction;
+    uint32_t defender_kind;
+    double   maintain_sla;
+    double   winning_reward, losing_reward;
+    /* ScanAndReimageCompromisedMachines(probability, scan_capacity, scan_frequency) */
+    double   scan_probability;
+    uint32_t scan_capacity, scan_frequency;
+    /* batching */
+    uint32_t auto_reset;             /* 1: an env that ends is re-initialised inside the same step (VecEnv semantics) */
+    uint32_t max_episode_steps;      /* 0 = unlimited; else `truncated` is raised at this step count */
+    uint32_t rng_kind;
+    uint32_t reserved0;
+    uint64_t seed;
+    uint64_t env_id_base;            /* global id of env 0 of this shard (multi-GPU: rank * n_envs) */
+} mcbs_batch_cfg;
+
+typedef struct mcbs_topology mcbs_topology;
+typedef struct mcbs_batch mcbs_batch;
+
+/* Observation buffers, marlon-flat layout = what AttackerEnvWrapper.transform_observation
+ * returns (marlon/baseline_models/env_wrappers/attack_wrapper.py:474-522; fields built at
+ * env.py:753-773,859-933).  Any pointer may be NULL to skip that field.  E = n_envs,
+ * N = maximum_node_count, C = maximum_total_credentials, K = max discoverable per action. */
+typedef struct mcbs_obs_buffers {
+    int32_t* scalars;                     /* [E,7]: newly_discovered_nodes_count, lateral_move, customer_data_found,
+                                             probe_result, escalation, credential_cache_length, discovered_node_count */
+    int32_t* leaked_credentials;          /* [E,K,4] rows (used, cache_idx, target ext idx, port idx) */
+    int32_t* credential_cache_matrix;     /* [E,C,2] rows (target ext idx, port idx) */
+    int32_t* discovered_nodes_properties; /* [E,N,n_props] */
+    int32_t* nodes_privilegelevel;        /* [E,N] */
+    int8_t*  mask_local;                  /* [E,N,L] */
+    int8_t*  mask_remote;                 /* [E,N,N,R] */
+    int8_t*  mask_connect;                /* [E,N,N,P,C] */
+    int8_t*  mask_discrete;               /* [E, N*N*P*C + N*L + N*N*R]: MaskedDiscreteAttackerWrapper.action_masks()
+                                             order (action_masking.py:96-110): connect, local, remote */
+} mcbs_obs_buffers;
+
+/* Per-step outputs of mcbs_step beyond reward/terminated (StepInfo, env.py:1176-1182). */
+typedef struct mcbs_info_buffers {
+    double*  network_availability; /* [E] */
+    int32_t* step_count;           /* [E] */
+    uint8_t* truncated;            /* [E] */
+    uint8_t* out_of_bound;         /* [E] 1 = OutOfBoundIndexError path was taken (env.py:1171-1174) */
+} mcbs_info_buffers;
+
+const char* mcbs_last_error(void);
+uint32_t    mcbs_abi_version(void);
+
+/* model.Environment (+ identifiers) -> device-resident tables.  Replaces the deep-copied
+ * networkx graph of env.py:375-376. */
+int  mcbs_topology_create(const void* blob, size_t nbytes, int32_t device, mcbs_topology** out);
+void mcbs_topology_destroy(mcbs_topology*);
+
+/* CyberBattleEnv.__init__ (env.py:470-566) for n_envs environments sharing one topology. */
+int  mcbs_batch_create(const mcbs_topology*, const mcbs_batch_cfg*, mcbs_batch** out);
+void mcbs_batch_destroy(mcbs_batch*);
+
+/* CyberBattleEnv.reset (env.py:1187-1209) for every env, or for the envs whose byte in the
+ * device array env_mask[E] is non-zero (NULL = all). */
+int  mcbs_reset(mcbs_batch*, const uint8_t* env_mask, void* stream);
+
+/* CyberBattleEnv.step (env.py:1145-1185) for all envs in one launch, observation excluded.
+ * actions: device int32 [E,5] rows (kind, a, b, c, d):
+ *     kind 0 local_vulnerability  (source, vuln)              -- action dict order of env.py:540-559
+ *     kind 1 remote_vulnerability (source, target, vuln)
+ *     kind 2 connect              (source, target, port, credential index)
+ * reward: device float [E]; terminated: device uint8 [E]; info may be NULL.
+ * An env that is done and not auto-reset is left untouched (reward 0, terminated 1): the
+ * single-env facade raises the reference's RuntimeError (env.py:1146-1147) on the host. */
+int  mcbs_step(mcbs_batch*, const int32_t* actions, float* reward, uint8_t* terminated,
+               const mcbs_info_buffers* info, void* stream);
+
+/* Same transition, but the observation is written exactly where the reference assembles it:
+ * after the attacker's action and BEFORE the defender acts (env.py:1153 vs 1156-1158).
+ * Three launches: attacker phase, observation, defender + goals. */
+int  mcbs_step_observe(mcbs_batch*, const int32_t* actions, float* reward, uint8_t* terminated,
+                       const mcbs_info_buffers* info, const mcbs_obs_buffers* obs, void* stream);
+
+/* Observation of the current state: the reset observation (env.py:1197-1200) right after
+ * mcbs_reset; otherwise the state-aggregated fields with the per-step flags of the last action. */
+int  mcbs_observe(mcbs_batch*, const mcbs_obs_buffers* obs, void* stream);
+
+/* StepInfo fields without stepping. */
+int  mcbs_step_info(mcbs_batch*, const mcbs_info_buffers* info, void* stream);
+
+/* Random-agent harness (env.py:935-1055): `valid` != 0 draws like sample_valid_action (source
+ * among owned nodes, target among discovered, rejection against the action mask); 0 draws every
+ * component uniformly in its bound, invalid actions included.  Philox stream separate from the
+ * defender's.  actions_out: device int32 [E,5]. */
+int  mcbs_sample_actions(mcbs_batch*, int32_t valid, uint64_t seed, uint64_t step, int32_t* actions_out, void* stream);
+
+/* Defender draw tape for MCBS_RNG_TAPE: device double [E, draws_per_step] consumed by the next
+ * step (scan draws first, then detection draws in consumption order). */
+int  mcbs_set_draw_tape(mcbs_batch*, const double* tape, uint32_t draws_per_step);
+
+/* Parity / debugging: canonical per-env state records (layout: mcbs_state_record below),
+ * host buffers, synchronous. */
+size_t mcbs_state_record_bytes(const mcbs_batch*);
+int  mcbs_get_state(mcbs_batch*, void* host_buf, size_t nbytes);
+int  mcbs_set_state(mcbs_batch*, const void* host_buf, size_t nbytes);
+
+/* Kernel timing hook for bench.py: HIP events recorded on `stream` around each mcbs_step launch
+ * while enabled; mcbs_timing_read synchronises and returns the summed kernel milliseconds. */
+int  mcbs_timing_enable(mcbs_batch*, int32_t on);
+int  mcbs_timing_read(mcbs_batch*, double* total_ms, uint64_t* launches);
+
+/* Canonical state record (host side, used by get/set_state and the oracle's dump):
+ * fixed header followed by n_nodes node records, the discovery order and the credential cache. */
+typedef struct mcbs_state_header { /* 64 bytes */
+    uint32_t step_count, done, truncated, episode;
+    uint32_t n_discovered, n_creds;
+    uint32_t last_outcome_kind, last_escalation;
+    uint32_t last_new_nodes, last_new_creds, last_oob, pad0;
+    double   cum_reward;
+    double   availability;
+} mcbs_state_header;
+
+typedef struct mcbs_state_node { /* 32 bytes */
+    uint64_t discovered_props;
+    uint32_t attacked_ever;   /* bit s: slot s exploited at least once (actions.py:396-407) */
+    uint32_t attacked_since;  /* bit s: ... since the node's last re-imaging */
+    uint8_t  discovered, installed, ever_owned, running;
+    uint8_t  privilege, tags, countdown, pad;
+    uint32_t pad1[2];
+} mcbs_state_node;
+/* followed by uint16 discovery_order[n_nodes] and uint16 credential_cache[max_total_credentials] (triple ids) */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCBS_H */

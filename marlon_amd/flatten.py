@@ -1,0 +1,390 @@
+"""Topology flattener: model.Environment -> "MCBT" table blob (include/mcbs.h).
+
+The reference keeps one Python/networkx graph of NodeInfo objects per environment and
+deep-copies it on every reset (cyberbattle_env.py:375-376).  Here the immutable part of an
+environment is lowered ONCE into flat tables shared by every env of a batch:
+
+  * per node: value, SLA weight, first-match-resolved firewall port masks (actions.py:504-515),
+    listening-port mask (actions.py:573), services with allowed credential ids (actions.py:608-621),
+    static property mask, initial ownership;
+  * per (node, vulnerability) "slot": outcome kind/payload, cost, and the precondition
+    pre-evaluated on that node's static properties for each of the 16 possible sets of
+    `privilege_k` tags (the only properties that change at run time, actions.py:378) ->
+    a 16-bit truth table, so the kernel never interprets an expression;
+  * credential strings and (node, port, credential) triples renamed to dense ids, so the
+    "gathered credentials" set (actions.py:142,291-293) and the credential cache de-duplication
+    (cyberbattle_env.py:882) become bit masks.
+
+Validation mirrors CyberBattleEnv.validate_environment (cyberbattle_env.py:408-465) and raises
+ValueError for the same defects, plus for run-time failures of the reference that a batched
+engine cannot surface per env (a vulnerability id whose type contradicts the identifier list it
+is named in, actions.py:357-358; leaked references to nodes that do not exist).
+
+Works on marlon_amd.model objects and, by duck typing on the reference's field names, on the
+reference's own model objects (how tests/golden/topology_*.bin were produced).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+from . import precondition as pc
+
+ABI_VERSION = 1
+TOPO_MAGIC = 0x5442434D
+
+MAX_NODES, MAX_PORTS, MAX_PROPS, MAX_SLOTS, MAX_LOCAL = 256, 32, 64, 32, 32
+MAX_CRED_STRINGS, MAX_TRIPLES = 1024, 4096
+
+OUT_NONE, OUT_LEAKED_CREDENTIALS, OUT_LEAKED_NODES, OUT_PRIVILEGE_ESCALATION, OUT_LATERAL_MOVE, \
+    OUT_CUSTOMER_DATA, OUT_PROBE_SUCCEEDED, OUT_PROBE_FAILED, OUT_EXPLOIT_FAILED, OUT_OTHER = range(10)
+
+NODE_INSTALLED0, NODE_REIMAGABLE = 1, 2
+TAG_NAMES = tuple(f"privilege_{k}" for k in range(4))
+
+HEADER_DT = np.dtype([
+    ("magic", "<u4"), ("abi_version", "<u4"), ("total_bytes", "<u4"), ("header_bytes", "<u4"),
+    ("n_nodes", "<u4"), ("n_ports", "<u4"), ("n_props", "<u4"), ("n_local", "<u4"), ("n_remote", "<u4"),
+    ("n_cred_strings", "<u4"), ("n_triples", "<u4"), ("max_slots", "<u4"),
+    ("n_slots_total", "<u4"), ("n_payload", "<u4"), ("n_services", "<u4"), ("n_allowed", "<u4"), ("n_code", "<u4"),
+    ("max_leak_per_action", "<u4"), ("avail_any_order", "<u4"), ("reserved0", "<u4"),
+    ("total_sla_weight", "<f8"), ("full_availability", "<f8"),
+    ("off_node", "<u4"), ("off_slot_of", "<u4"), ("off_slot", "<u4"), ("off_payload", "<u4"),
+    ("off_service", "<u4"), ("off_allowed", "<u4"), ("off_triple", "<u4"), ("off_code", "<u4"),
+    ("off_init_order", "<u4"), ("n_init_owned", "<u4"), ("reserved", "<u4", (14,)),
+])
+NODE_DT = np.dtype([
+    ("props", "<u8"), ("sla_weight", "<f8"), ("avail_term", "<f8"), ("value", "<i4"),
+    ("fw_in_allow", "<u4"), ("fw_out_allow", "<u4"), ("listen", "<u4"), ("local_mask", "<u4"),
+    ("svc_off", "<u2"), ("svc_cnt", "<u2"), ("flags", "u1"), ("priv0", "u1"), ("tags0", "u1"), ("n_slots", "u1"),
+    ("pad", "<u4", (3,)),
+])
+SLOT_DT = np.dtype([
+    ("cost", "<f8"), ("probe_mask", "<u8"), ("payload_off", "<u4"), ("payload_cnt", "<u2"), ("precond_tt", "<u2"),
+    ("code_off", "<u4"), ("code_len", "<u2"), ("kind", "u1"), ("level", "u1"),
+])
+PAYLOAD_DT = np.dtype([("node", "<u2"), ("cred", "<u2"), ("triple", "<u2"), ("port", "<u2")])
+SERVICE_DT = np.dtype([("sla_weight", "<f8"), ("allowed_off", "<u2"), ("allowed_cnt", "<u2"),
+                       ("port", "u1"), ("running", "u1"), ("pad", "<u2")])
+TRIPLE_DT = np.dtype([("node", "<u2"), ("cred", "<u2"), ("port", "<u2"), ("pad", "<u2")])
+assert HEADER_DT.itemsize == 192 and NODE_DT.itemsize == 64 and SLOT_DT.itemsize == 32
+assert PAYLOAD_DT.itemsize == 8 and SERVICE_DT.itemsize == 16 and TRIPLE_DT.itemsize == 8
+
+
+def _class_names(obj) -> List[str]:
+    return [c.__name__ for c in type(obj).__mro__]
+
+
+def _outcome_kind(outcome) -> int:
+    names = _class_names(outcome) if outcome is not None else []
+    for name, kind in (("LeakedCredentials", OUT_LEAKED_CREDENTIALS), ("LeakedNodesId", OUT_LEAKED_NODES),
+                       ("PrivilegeEscalation", OUT_PRIVILEGE_ESCALATION), ("LateralMove", OUT_LATERAL_MOVE),
+                       ("CustomerData", OUT_CUSTOMER_DATA), ("ProbeSucceeded", OUT_PROBE_SUCCEEDED),
+                       ("ProbeFailed", OUT_PROBE_FAILED), ("ExploitFailed", OUT_EXPLOIT_FAILED)):
+        if name in names:
+            return kind
+    return OUT_OTHER
+
+
+def _is_remote(vuln) -> bool:
+    return getattr(vuln.type, "name", str(vuln.type)) == "REMOTE"
+
+
+def _is_allow(rule) -> bool:
+    return getattr(rule.permission, "name", str(rule.permission)) == "ALLOW"
+
+
+def _expr_of(vuln) -> pc.BoolExpr:
+    expr = vuln.precondition.expression
+    return expr if isinstance(expr, pc.BoolExpr) else pc.parse_expression(str(expr))
+
+
+@dataclass
+class FlatTopology:
+    """Result of flatten(): the blob plus the name tables needed to talk about it."""
+    blob: bytes
+    node_ids: List[str]
+    ports: List[str]
+    properties: List[str]
+    local_vulnerabilities: List[str]
+    remote_vulnerabilities: List[str]
+    credential_strings: List[str]
+    triples: List[Tuple[str, str, str]]
+    max_slots: int
+    max_leak_per_action: int
+    initial_owned: List[int]
+
+    @property
+    def n_nodes(self) -> int:
+        return len(self.node_ids)
+
+    def header(self) -> np.ndarray:
+        return np.frombuffer(self.blob, dtype=HEADER_DT, count=1)[0]
+
+    def section(self, name: str, dtype, count: int) -> np.ndarray:
+        off = int(self.header()["off_" + name])
+        return np.frombuffer(self.blob, dtype=dtype, count=count, offset=off)
+
+    def node_table(self) -> np.ndarray:
+        return self.section("node", NODE_DT, self.n_nodes)
+
+    def slot_table(self) -> np.ndarray:
+        return self.section("slot", SLOT_DT, self.n_nodes * self.max_slots).reshape(self.n_nodes, self.max_slots)
+
+    def slot_of(self) -> np.ndarray:
+        w = len(self.local_vulnerabilities) + len(self.remote_vulnerabilities)
+        return self.section("slot_of", np.uint8, self.n_nodes * w).reshape(self.n_nodes, w)
+
+
+def _first_match_mask(rules, ports: List[str]) -> int:
+    mask = 0
+    for p, port in enumerate(ports):
+        for rule in rules:
+            if rule.port == port:
+                if _is_allow(rule):
+                    mask |= 1 << p
+                break
+    return mask
+
+
+def flatten(environment) -> FlatTopology:
+    ids = environment.identifiers
+    ports, props = list(ids.ports), list(ids.properties)
+    local_ids, remote_ids = list(ids.local_vulnerabilities), list(ids.remote_vulnerabilities)
+    library: Dict[str, object] = dict(environment.vulnerability_library)
+    nodes = [(nid, info) for nid, info in environment.nodes()]
+    node_ids = [nid for nid, _ in nodes]
+    node_index = {nid: i for i, nid in enumerate(node_ids)}
+    N, P, L, R = len(nodes), len(ports), len(local_ids), len(remote_ids)
+
+    # -- the reference's own asserts (env.py:411-414) and limits of this engine --
+    if not ports or not props or not local_ids or not remote_ids:
+        raise ValueError("identifiers must declare at least one port, property, local and remote vulnerability")
+    if N == 0:
+        raise ValueError("empty network")
+    for what, n, cap in (("nodes", N, MAX_NODES), ("ports", P, MAX_PORTS), ("properties", len(props), MAX_PROPS),
+                         ("local vulnerabilities", L, MAX_LOCAL)):
+        if n > cap:
+            raise ValueError(f"topology has {n} {what}; the engine supports at most {cap}")
+
+    prop_index: Dict[str, int] = {}
+    for i, p in enumerate(props):
+        prop_index.setdefault(p, i)          # list.index semantics: first occurrence (actions.py:235)
+    port_index: Dict[str, int] = {}
+    for i, p in enumerate(ports):
+        port_index.setdefault(p, i)
+
+    all_vulns = [(None, vid, v) for vid, v in library.items()]
+    all_vulns += [(i, vid, v) for i, (_, info) in enumerate(nodes) for vid, v in info.vulnerabilities.items()]
+
+    # -- validate_environment (env.py:437-465) --
+    used_ports = {s.name for _, info in nodes for s in info.services}
+    used_ports |= {c.port for _, _, v in all_vulns if _outcome_kind(v.outcome) == OUT_LEAKED_CREDENTIALS
+                   for c in v.outcome.credentials}
+    bad = used_ports.difference(ports)
+    if bad:
+        raise ValueError(f"The network has references to undefined port names: {bad}")
+    bad = {p for _, info in nodes for p in info.properties}.difference(props)
+    if bad:
+        raise ValueError(f"The network has references to undefined property names: {bad}")
+    bad = {vid for _, vid, v in all_vulns if not _is_remote(v)}.difference(local_ids)
+    if bad:
+        raise ValueError(f"The network has references to undefined local vulnerability names: {bad}")
+    bad = {vid for _, vid, v in all_vulns if _is_remote(v)}.difference(remote_ids)
+    if bad:
+        raise ValueError(f"The network has references to undefined remote vulnerability names: {bad}")
+
+    # -- credential strings and triples, first-appearance order (library, then nodes in order) --
+    cred_index: Dict[str, int] = {}
+    triple_index: Dict[Tuple[str, str, str], int] = {}
+    max_leak = 0
+    for _, vid, v in all_vulns:
+        kind = _outcome_kind(v.outcome)
+        if kind == OUT_LEAKED_CREDENTIALS:
+            max_leak = max(max_leak, len(v.outcome.credentials))
+            for c in v.outcome.credentials:
+                if c.node not in node_index:
+                    raise ValueError(f"vulnerability '{vid}' leaks a credential for unknown node '{c.node}'")
+                cred_index.setdefault(c.credential, len(cred_index))
+                triple_index.setdefault((c.node, c.port, c.credential), len(triple_index))
+        elif kind == OUT_LEAKED_NODES:
+            for n in v.outcome.nodes:
+                if n not in node_index:
+                    raise ValueError(f"vulnerability '{vid}' leaks unknown node id '{n}'")
+    if len(cred_index) > MAX_CRED_STRINGS or len(triple_index) > MAX_TRIPLES:
+        raise ValueError("too many distinct credentials for the engine")
+
+    node_tab = np.zeros(N, NODE_DT)
+    slot_of = np.full((N, L + R), 0xFF, np.uint8)
+    per_node_slots: List[List[Tuple[str, object]]] = []
+    for i, (nid, info) in enumerate(nodes):
+        merged: Dict[str, object] = dict(library)            # library shadows the node's own dict (actions.py:342-345)
+        for vid, v in info.vulnerabilities.items():
+            merged.setdefault(vid, v)
+        per_node_slots.append(list(merged.items()))
+    V = max(1, max(len(s) for s in per_node_slots))
+    if V > MAX_SLOTS:
+        raise ValueError(f"a node carries {V} vulnerabilities; the engine supports at most {MAX_SLOTS}")
+
+    slot_tab = np.zeros((N, V), SLOT_DT)
+    payload: List[Tuple[int, int, int, int]] = []
+    services: List[Tuple[float, int, int, int, int]] = []
+    allowed: List[int] = []
+    code = bytearray()
+    terms: List[float] = []
+
+    for i, (nid, info) in enumerate(nodes):
+        rec = node_tab[i]
+        static_names = list(info.properties)
+        tags0 = sum(1 << k for k, t in enumerate(TAG_NAMES) if t in static_names)
+        rec["props"] = sum(1 << prop_index[p] for p in set(static_names) if p not in TAG_NAMES)
+        rec["tags0"] = tags0
+        rec["value"] = int(info.value)
+        rec["sla_weight"] = float(info.sla_weight)
+        rec["fw_in_allow"] = _first_match_mask(info.firewall.incoming, ports)
+        rec["fw_out_allow"] = _first_match_mask(info.firewall.outgoing, ports)
+        rec["listen"] = sum(1 << port_index[s] for s in {s.name for s in info.services})
+        rec["local_mask"] = sum(1 << l for l, vid in enumerate(local_ids) if vid in library or vid in info.vulnerabilities)
+        installed = bool(info.agent_installed)
+        priv0 = int(info.privilege_level)
+        if installed:
+            priv0 = max(priv0, 1)                               # actions.py:149-152 -> __mark_node_as_owned(LocalUser)
+        elif priv0 != 0:
+            raise ValueError(f"node '{nid}' starts with privilege {priv0} but no agent installed")
+        rec["flags"] = (NODE_INSTALLED0 if installed else 0) | (NODE_REIMAGABLE if info.reimagable else 0)
+        rec["priv0"] = priv0
+
+        # services + availability term, same operation order as actions.py:731-743
+        rec["svc_off"] = len(services)
+        rec["svc_cnt"] = len(info.services)
+        total_w, running_w = 0, 0
+        for s in info.services:
+            w = s.sla_weight
+            total_w += w
+            running_w += w * int(s.running)
+            ids_allowed = [cred_index[c] for c in s.allowedCredentials if c in cred_index]
+            services.append((float(w), len(allowed), len(ids_allowed), port_index[s.name], int(bool(s.running))))
+            allowed.extend(ids_allowed)
+        term = ((1 + running_w) / (1 + total_w)) * info.sla_weight
+        rec["avail_term"] = term
+        terms.append(float(term))
+
+        # vulnerability slots
+        rec["n_slots"] = len(per_node_slots[i])
+        for s, (vid, v) in enumerate(per_node_slots[i]):
+            remote = _is_remote(v)
+            listed = remote_ids if remote else local_ids
+            other = local_ids if remote else remote_ids
+            if vid in other:
+                raise ValueError(f"vulnerability id '{vid}' is for an attack of type {v.type} but is also declared in "
+                                 f"the other identifier list (the reference raises at run time, actions.py:357-358)")
+            for idx, name in enumerate(listed):
+                if name == vid:
+                    slot_of[i, (L if remote else 0) + idx] = s
+            kind = _outcome_kind(v.outcome)
+            sl = slot_tab[i, s]
+            sl["kind"] = kind
+            sl["cost"] = float(v.cost)
+            expr = _expr_of(v)
+            tt = 0
+            for t in range(16):
+                names = set(static_names) | {TAG_NAMES[k] for k in range(4) if t >> k & 1}
+                if expr.evaluate(names):
+                    tt |= 1 << t
+            sl["precond_tt"] = tt
+            bc = pc.encode(expr, prop_index, TAG_NAMES)
+            sl["code_off"], sl["code_len"] = len(code), len(bc)
+            code += bc
+            sl["payload_off"] = len(payload)
+            if kind == OUT_LEAKED_CREDENTIALS:
+                for c in v.outcome.credentials:
+                    payload.append((node_index[c.node], cred_index[c.credential],
+                                    triple_index[(c.node, c.port, c.credential)], port_index[c.port]))
+                sl["payload_cnt"] = len(v.outcome.credentials)
+            elif kind == OUT_LEAKED_NODES:
+                for n in v.outcome.nodes:
+                    payload.append((node_index[n], 0, 0, 0))
+                sl["payload_cnt"] = len(v.outcome.nodes)
+            elif kind == OUT_PRIVILEGE_ESCALATION:
+                level = int(v.outcome.level)
+                if not 0 <= level <= 3:
+                    raise ValueError(f"vulnerability '{vid}': privilege level {level} out of range")
+                sl["level"] = level
+            elif kind == OUT_PROBE_SUCCEEDED:
+                mask = 0
+                for p in v.outcome.discovered_properties:
+                    if p not in static_names:
+                        if tt:   # reachable: the reference asserts at run time (actions.py:387-388)
+                            raise ValueError(f"Discovered property {p} must belong to the set of properties "
+                                             f"associated with the node ('{nid}', vulnerability '{vid}')")
+                        continue
+                    if p not in TAG_NAMES:
+                        mask |= 1 << prop_index[p]
+                sl["probe_mask"] = mask
+
+    # availability bookkeeping (actions.py:728-745)
+    total_weight = 0
+    full = 0
+    for (_, info), term in zip(nodes, terms):
+        total_weight += info.sla_weight
+        full += term
+    total_weight = float(total_weight)
+    if total_weight == 0.0:
+        raise ValueError("sum of node sla weights is zero (the reference divides by it)")
+    full_avail = float(full) / total_weight
+    denom = 1
+    for t in terms:
+        denom = max(denom, float(t).as_integer_ratio()[1])
+    any_order = int(all(t >= 0 for t in terms) and sum(int(t * denom) for t in terms) < 2 ** 53)
+
+    init_owned = [i for i, (_, info) in enumerate(nodes) if info.agent_installed]
+    init_order = np.full(N, 0xFF, np.uint8)
+    init_order[:len(init_owned)] = init_owned
+
+    payload_arr = np.array(payload, dtype=np.uint16).reshape(-1, 4)
+    payload_tab = np.zeros(len(payload), PAYLOAD_DT)
+    if len(payload):
+        for k, f in enumerate(("node", "cred", "triple", "port")):
+            payload_tab[f] = payload_arr[:, k]
+    service_tab = np.zeros(len(services), SERVICE_DT)
+    for k, (w, off, cnt, port, running) in enumerate(services):
+        service_tab[k] = (w, off, cnt, port, running, 0)
+    triple_tab = np.zeros(len(triple_index), TRIPLE_DT)
+    for (n, p, c), k in triple_index.items():
+        triple_tab[k] = (node_index[n], cred_index[c], port_index[p], 0)
+
+    sections = [
+        ("node", node_tab.tobytes()), ("slot_of", slot_of.tobytes()), ("slot", slot_tab.tobytes()),
+        ("payload", payload_tab.tobytes()), ("service", service_tab.tobytes()),
+        ("allowed", np.array(allowed, np.uint16).tobytes()), ("triple", triple_tab.tobytes()),
+        ("code", bytes(code)), ("init_order", init_order.tobytes()),
+    ]
+    hdr = np.zeros(1, HEADER_DT)
+    h = hdr[0]
+    body = bytearray()
+    base = HEADER_DT.itemsize
+    for name, data in sections:
+        pad = (-(base + len(body))) % 16
+        body += b"\0" * pad
+        h["off_" + name] = base + len(body)
+        body += data
+    body += b"\0" * ((-(base + len(body))) % 16)
+    h["magic"], h["abi_version"], h["header_bytes"] = TOPO_MAGIC, ABI_VERSION, base
+    h["total_bytes"] = base + len(body)
+    h["n_nodes"], h["n_ports"], h["n_props"], h["n_local"], h["n_remote"] = N, P, len(props), L, R
+    h["n_cred_strings"], h["n_triples"], h["max_slots"] = len(cred_index), len(triple_index), V
+    h["n_slots_total"] = N * V
+    h["n_payload"], h["n_services"], h["n_allowed"], h["n_code"] = len(payload), len(services), len(allowed), len(code)
+    h["max_leak_per_action"] = max_leak
+    h["avail_any_order"] = any_order
+    h["total_sla_weight"], h["full_availability"] = total_weight, full_avail
+    h["n_init_owned"] = len(init_owned)
+    blob = hdr.tobytes() + bytes(body)
+
+    return FlatTopology(
+        blob=blob, node_ids=node_ids, ports=ports, properties=props,
+        local_vulnerabilities=local_ids, remote_vulnerabilities=remote_ids,
+        credential_strings=list(cred_index), triples=list(triple_index),
+        max_slots=V, max_leak_per_action=max_leak, initial_owned=init_owned)
