@@ -159,7 +159,8 @@ typedef struct mcbs_triple { /* 8 bytes */
 #define MCBS_DEFENDER_NONE 0
 #define MCBS_DEFENDER_SCAN_AND_REIMAGE 1 /* ScanAndReimageCompromisedMachines */
 
-#define MCBS_RNG_PHILOX 0 /* draws = Philox4x32-10(key=(seed, global env id), ctr=(step, pair#, episode, 0)) */
+#define MCBS_RNG_PHILOX 0 /* draw i of a step = half (i&1) of Philox4x32-10(key = (seed lo, seed hi ^ env id hi),
+                             ctr = (global env id lo, episode, step_count, i>>1)), 53-bit doubles (hi>>5, lo>>6) */
 #define MCBS_RNG_TAPE   1 /* draws read from a caller tape (parity against the reference's global RNGs) */
 
 typedef struct mcbs_batch_cfg {
@@ -219,6 +220,8 @@ typedef struct mcbs_info_buffers {
     int32_t* step_count;           /* [E] */
     uint8_t* truncated;            /* [E] */
     uint8_t* out_of_bound;         /* [E] 1 = OutOfBoundIndexError path was taken (env.py:1171-1174) */
+    float*   raw_reward;           /* [E] ActionResult.reward before the clamp / terminal override of env.py:1162-1169
+                                      (0 on the out-of-bound path); parity and reward-shaping aid */
 } mcbs_info_buffers;
 
 const char* mcbs_last_error(void);

@@ -1,0 +1,174 @@
+"""ctypes front end of the CPU oracle (oracle/cbs_oracle.c).  TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
+product package (marlon_amd/) never does.  `build()` compiles the C restatement with gcc.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+import numpy as np
+
+from marlon_amd._abi import BatchCfg, EnvSpec, ObsBuffers, split_state, state_record_bytes
+from marlon_amd.flatten import FlatTopology
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "libcbs_oracle.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "cbs_oracle.c")
+    hdr = os.path.join(_HERE, "..", "include", "mcbs.h")
+    stale = (not os.path.exists(_LIB_PATH)) or any(
+        os.path.exists(p) and os.path.getmtime(p) > os.path.getmtime(_LIB_PATH) for p in (src, hdr))
+    if force or stale:
+        if not os.path.exists(src):
+            raise RuntimeError("oracle source missing")
+        subprocess.run(["make", "-C", _HERE], check=True, capture_output=True)
+    return _LIB_PATH
+
+
+def _load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    lib = C.CDLL(build())
+    lib.cbo_create.restype = C.c_void_p
+    lib.cbo_create.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(BatchCfg)]
+    lib.cbo_destroy.argtypes = [C.c_void_p]
+    lib.cbo_reset.argtypes = [C.c_void_p, C.c_int]
+    lib.cbo_observe.argtypes = [C.c_void_p, C.c_int, C.POINTER(ObsBuffers), C.c_int]
+    lib.cbo_step.restype = C.c_int
+    lib.cbo_step.argtypes = [C.c_void_p] + [C.c_void_p] * 9 + [C.c_int, C.c_void_p]
+    for name, n in (("cbo_exploit_local", 4), ("cbo_exploit_remote", 5), ("cbo_connect", 6)):
+        getattr(lib, name).argtypes = [C.c_void_p] + [C.c_int] * (n - 1) + [C.POINTER(C.c_double)]
+    lib.cbo_check_prerequisites.restype = C.c_int
+    lib.cbo_check_prerequisites.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    lib.cbo_node_has_tag.restype = C.c_int
+    lib.cbo_node_has_tag.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    lib.cbo_reimage_node.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.cbo_state_record_bytes.restype = C.c_size_t
+    lib.cbo_state_record_bytes.argtypes = [C.c_void_p]
+    lib.cbo_get_state.argtypes = [C.c_void_p, C.c_void_p]
+    lib.cbo_philox.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    _lib = lib
+    return lib
+
+
+def philox4x32_10(ctr, key) -> np.ndarray:
+    lib = _load()
+    c = np.asarray(ctr, dtype=np.uint32)
+    k = np.asarray(key, dtype=np.uint32)
+    out = np.zeros(4, np.uint32)
+    lib.cbo_philox(c.ctypes.data, k.ctypes.data, out.ctypes.data)
+    return out
+
+
+def obs_shapes(topo: FlatTopology, spec: EnvSpec) -> dict:
+    N, C_, K = spec.maximum_node_count, spec.maximum_total_credentials, spec.maximum_discoverable_credentials_per_action
+    L, R, P = len(topo.local_vulnerabilities), len(topo.remote_vulnerabilities), len(topo.ports)
+    return {
+        "scalars": ((7,), np.int32), "leaked_credentials": ((K, 4), np.int32),
+        "credential_cache_matrix": ((C_, 2), np.int32), "discovered_nodes_properties": ((N, len(topo.properties)), np.int32),
+        "nodes_privilegelevel": ((N,), np.int32), "mask_local": ((N, L), np.int8),
+        "mask_remote": ((N, N, R), np.int8), "mask_connect": ((N, N, P, C_), np.int8),
+    }
+
+
+class Oracle:
+    """n_envs independent reference-semantics environments over one flattened topology."""
+
+    def __init__(self, topo: FlatTopology, spec: EnvSpec):
+        self.lib = _load()
+        self.topo, self.spec = topo, spec
+        if topo.n_nodes > spec.maximum_node_count:
+            raise ValueError(f"Network node count ({topo.n_nodes}) exceeds the specified limit of {spec.maximum_node_count}.")
+        self._cfg = spec.to_cfg()
+        self._blob = np.frombuffer(topo.blob, dtype=np.uint8).copy()
+        self.h = self.lib.cbo_create(self._blob.ctypes.data, self._blob.size, C.byref(self._cfg))
+        if not self.h:
+            raise RuntimeError("cbo_create failed (bad blob or bounds)")
+        self.E = spec.n_envs
+        self._shapes = obs_shapes(topo, spec)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.cbo_destroy(self.h)
+            self.h = None
+
+    def alloc_obs(self, fields=None) -> dict:
+        fields = fields or list(self._shapes)
+        return {f: np.zeros((self.E,) + self._shapes[f][0], self._shapes[f][1]) for f in fields}
+
+    @staticmethod
+    def _obs_struct(obs: Optional[dict]) -> Optional[ObsBuffers]:
+        if obs is None:
+            return None
+        b = ObsBuffers()
+        for f, arr in obs.items():
+            setattr(b, f, arr.ctypes.data)
+        return b
+
+    def reset(self, env: Optional[int] = None) -> None:
+        for i in (range(self.E) if env is None else [env]):
+            self.lib.cbo_reset(self.h, i)
+
+    def observe(self, obs: dict, reset_obs: bool = False) -> dict:
+        b = self._obs_struct(obs)
+        for i in range(self.E):
+            self.lib.cbo_observe(self.h, i, C.byref(b), int(reset_obs))
+        return obs
+
+    def step(self, actions: np.ndarray, tape: Optional[np.ndarray] = None, obs: Optional[dict] = None) -> dict:
+        a = np.ascontiguousarray(actions, dtype=np.int32).reshape(self.E, 5)
+        out = dict(reward=np.zeros(self.E, np.float64), terminated=np.zeros(self.E, np.uint8),
+                   truncated=np.zeros(self.E, np.uint8), oob=np.zeros(self.E, np.uint8),
+                   step_count=np.zeros(self.E, np.int32), availability=np.zeros(self.E, np.float64),
+                   raw_reward=np.zeros(self.E, np.float64))
+        t_ptr, dps = None, 0
+        if tape is not None:
+            tape = np.ascontiguousarray(tape, dtype=np.float64).reshape(self.E, -1)
+            t_ptr, dps = tape.ctypes.data, tape.shape[1]
+        b = self._obs_struct(obs)
+        out["errors"] = self.lib.cbo_step(
+            self.h, a.ctypes.data, out["reward"].ctypes.data, out["terminated"].ctypes.data, out["truncated"].ctypes.data,
+            out["oob"].ctypes.data, out["step_count"].ctypes.data, out["availability"].ctypes.data,
+            out["raw_reward"].ctypes.data, t_ptr, dps,
+            C.byref(b) if b is not None else None)
+        return out
+
+    # -- actuator level (AgentActions without the gym env) --
+    def exploit_local(self, node: int, local_idx: int, env: int = 0):
+        out = (C.c_double * 2)()
+        self.lib.cbo_exploit_local(self.h, env, node, local_idx, out)
+        return out[0], int(out[1])
+
+    def exploit_remote(self, source: int, target: int, remote_idx: int, env: int = 0):
+        out = (C.c_double * 2)()
+        self.lib.cbo_exploit_remote(self.h, env, source, target, remote_idx, out)
+        return out[0], int(out[1])
+
+    def connect(self, source: int, target: int, port: int, cred: int, env: int = 0):
+        out = (C.c_double * 2)()
+        self.lib.cbo_connect(self.h, env, source, target, port, cred, out)
+        return out[0], int(out[1])
+
+    def check_prerequisites(self, node: int, vuln_col: int, env: int = 0) -> int:
+        return self.lib.cbo_check_prerequisites(self.h, env, node, vuln_col)
+
+    def node_has_tag(self, node: int, level: int, env: int = 0) -> bool:
+        return bool(self.lib.cbo_node_has_tag(self.h, env, node, level))
+
+    def reimage_node(self, node: int, env: int = 0) -> None:
+        self.lib.cbo_reimage_node(self.h, env, node)
+
+    def get_state(self):
+        rb = state_record_bytes(self.topo.n_nodes, self.spec.maximum_total_credentials)
+        assert rb == self.lib.cbo_state_record_bytes(self.h)
+        buf = np.zeros(rb * self.E, np.uint8)
+        self.lib.cbo_get_state(self.h, buf.ctypes.data)
+        return split_state(buf, self.E, self.topo.n_nodes, self.spec.maximum_total_credentials)
