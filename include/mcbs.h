@@ -101,7 +101,8 @@ typedef struct mcbs_topo_header { /* 192 bytes */
     uint32_t off_code;            /* uint8[n_code] precondition byte code */
     uint32_t off_init_order;      /* uint8[n_nodes]: nodes owned at reset, network order, then 0xFF */
     uint32_t n_init_owned;
-    uint32_t reserved[14];
+    double   full_sum;            /* node-order sum of every avail_term (numerator of full_availability) */
+    uint32_t reserved[12];
 } mcbs_topo_header;
 
 typedef struct mcbs_node_static { /* 64 bytes */

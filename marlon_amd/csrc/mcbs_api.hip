@@ -1,0 +1,485 @@
+// mcbs_api.hip — host side of the C ABI declared in include/mcbs.h (libmcbs.so).
+// One translation unit: the kernels are included below.  Build: marlon_amd/csrc/Makefile (hipcc, gfx950).
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "mcbs.h"
+#include "mcbs_device.h"
+#include "mcbs_step.hip"
+#include "mcbs_obs.hip"
+#include "mcbs_aux.hip"
+
+using namespace mcbs;
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                     \
+    do {                                                                                                  \
+        hipError_t _e = (expr);                                                                           \
+        if (_e != hipSuccess) return fail(MCBS_EHIP, "%s failed: %s", #expr, hipGetErrorString(_e));      \
+    } while (0)
+
+struct mcbs_topology {
+    std::vector<uint8_t> host;
+    uint8_t* dev = nullptr;
+    int32_t device = 0;
+    const mcbs_topo_header* H() const { return reinterpret_cast<const mcbs_topo_header*>(host.data()); }
+};
+
+struct mcbs_batch {
+    const mcbs_topology* topo = nullptr;
+    mcbs_batch_cfg cfg{};
+    DevState S{};
+    Topo T{};
+    StepCfg C{};
+    uint8_t* arena = nullptr;       // every per-env column + bodies + init body, one allocation
+    size_t arena_bytes = 0;
+    ObsDigest* digest = nullptr;
+    const double* tape = nullptr;
+    uint32_t tape_dps = 0;
+    // timing
+    bool timing = false;
+    std::vector<hipEvent_t> ev;     // pairs (start, stop) per launch
+    size_t ev_used = 0;
+    double timed_ms = 0.0;
+    uint64_t timed_launches = 0;
+};
+
+extern "C" const char* mcbs_last_error(void) { return g_err; }
+extern "C" uint32_t mcbs_abi_version(void) { return MCBS_ABI_VERSION; }
+
+// ------------------------------------------------------------------ topology
+static int check_section(const mcbs_topo_header* h, uint32_t off, size_t bytes, const char* name) {
+    if (off % 16u || (size_t)off + bytes > h->total_bytes) return fail(MCBS_EINVAL, "topology blob: section %s out of range", name);
+    return MCBS_OK;
+}
+
+extern "C" int mcbs_topology_create(const void* blob, size_t nbytes, int32_t device, mcbs_topology** out) {
+    if (!blob || !out) return fail(MCBS_EINVAL, "null argument");
+    if (nbytes < sizeof(mcbs_topo_header)) return fail(MCBS_EINVAL, "topology blob too small");
+    const mcbs_topo_header* h = static_cast<const mcbs_topo_header*>(blob);
+    if (h->magic != MCBS_TOPO_MAGIC) return fail(MCBS_EINVAL, "topology blob: bad magic");
+    if (h->abi_version != MCBS_ABI_VERSION) return fail(MCBS_EINVAL, "topology blob: ABI version %u, library %u", h->abi_version, MCBS_ABI_VERSION);
+    if (h->total_bytes != nbytes || h->header_bytes != sizeof(mcbs_topo_header)) return fail(MCBS_EINVAL, "topology blob: size mismatch");
+    if (h->n_nodes == 0 || h->n_nodes > MCBS_MAX_NODES) return fail(MCBS_ELIMIT, "n_nodes %u outside 1..%d", h->n_nodes, MCBS_MAX_NODES);
+    if (h->n_ports == 0 || h->n_ports > MCBS_MAX_PORTS || h->n_props > MCBS_MAX_PROPS || h->max_slots == 0 || h->max_slots > MCBS_MAX_SLOTS ||
+        h->n_local == 0 || h->n_local > MCBS_MAX_LOCAL_VULNS || h->n_remote == 0 || h->n_cred_strings > MCBS_MAX_CRED_STRINGS ||
+        h->n_triples > MCBS_MAX_TRIPLES)
+        return fail(MCBS_ELIMIT, "topology exceeds an engine limit");
+    int rc;
+    if ((rc = check_section(h, h->off_node, sizeof(mcbs_node_static) * h->n_nodes, "node"))) return rc;
+    if ((rc = check_section(h, h->off_slot_of, (size_t)h->n_nodes * (h->n_local + h->n_remote), "slot_of"))) return rc;
+    if ((rc = check_section(h, h->off_slot, sizeof(mcbs_vuln_slot) * h->n_nodes * h->max_slots, "slot"))) return rc;
+    if ((rc = check_section(h, h->off_payload, sizeof(mcbs_payload) * h->n_payload, "payload"))) return rc;
+    if ((rc = check_section(h, h->off_service, sizeof(mcbs_service) * h->n_services, "service"))) return rc;
+    if ((rc = check_section(h, h->off_allowed, sizeof(uint16_t) * h->n_allowed, "allowed"))) return rc;
+    if ((rc = check_section(h, h->off_triple, sizeof(mcbs_triple) * h->n_triples, "triple"))) return rc;
+    if ((rc = check_section(h, h->off_init_order, h->n_nodes, "init_order"))) return rc;
+    // every index the kernels will dereference is range-checked here, once, on the host
+    const uint8_t* b = static_cast<const uint8_t*>(blob);
+    const mcbs_node_static* ns = reinterpret_cast<const mcbs_node_static*>(b + h->off_node);
+    const mcbs_vuln_slot* sl = reinterpret_cast<const mcbs_vuln_slot*>(b + h->off_slot);
+    const mcbs_payload* pl = reinterpret_cast<const mcbs_payload*>(b + h->off_payload);
+    const mcbs_service* sv = reinterpret_cast<const mcbs_service*>(b + h->off_service);
+    const uint8_t* so = b + h->off_slot_of;
+    for (uint32_t n = 0; n < h->n_nodes; ++n) {
+        if ((uint32_t)ns[n].svc_off + ns[n].svc_cnt > h->n_services) return fail(MCBS_EINVAL, "node %u: service range", n);
+        if (ns[n].n_slots > h->max_slots) return fail(MCBS_EINVAL, "node %u: slot count", n);
+        for (uint32_t c = 0; c < h->n_local + h->n_remote; ++c) {
+            const uint8_t s = so[(size_t)n * (h->n_local + h->n_remote) + c];
+            if (s != 0xFF && s >= ns[n].n_slots) return fail(MCBS_EINVAL, "node %u: slot_of out of range", n);
+        }
+        for (uint32_t s = 0; s < ns[n].n_slots; ++s) {
+            const mcbs_vuln_slot& v = sl[(size_t)n * h->max_slots + s];
+            if ((size_t)v.payload_off + v.payload_cnt > h->n_payload) return fail(MCBS_EINVAL, "node %u slot %u: payload range", n, s);
+            if (v.level > 3 || v.kind > MCBS_OUT_OTHER) return fail(MCBS_EINVAL, "node %u slot %u: bad kind/level", n, s);
+            if (v.payload_cnt > 1023) return fail(MCBS_ELIMIT, "node %u slot %u: payload too long", n, s);
+        }
+    }
+    for (uint32_t i = 0; i < h->n_payload; ++i)
+        if (pl[i].node >= h->n_nodes || (h->n_cred_strings && pl[i].cred >= h->n_cred_strings && pl[i].cred != 0) ||
+            (h->n_triples && pl[i].triple >= h->n_triples && pl[i].triple != 0) || pl[i].port >= h->n_ports)
+            return fail(MCBS_EINVAL, "payload %u out of range", i);
+    for (uint32_t i = 0; i < h->n_services; ++i)
+        if ((uint32_t)sv[i].allowed_off + sv[i].allowed_cnt > h->n_allowed || sv[i].port >= h->n_ports)
+            return fail(MCBS_EINVAL, "service %u out of range", i);
+    const mcbs_triple* tr = reinterpret_cast<const mcbs_triple*>(b + h->off_triple);
+    for (uint32_t i = 0; i < h->n_triples; ++i)
+        if (tr[i].node >= h->n_nodes || tr[i].cred >= h->n_cred_strings || tr[i].port >= h->n_ports)
+            return fail(MCBS_EINVAL, "triple %u out of range", i);
+    const uint8_t* io = b + h->off_init_order;
+    if (h->n_init_owned > h->n_nodes) return fail(MCBS_EINVAL, "init order");
+    for (uint32_t i = 0; i < h->n_init_owned; ++i) if (io[i] >= h->n_nodes) return fail(MCBS_EINVAL, "init order");
+
+    mcbs_topology* t = new (std::nothrow) mcbs_topology();
+    if (!t) return fail(MCBS_ENOMEM, "out of memory");
+    t->host.assign(b, b + nbytes);
+    t->device = device;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipMalloc(&t->dev, nbytes);
+    if (e == hipSuccess) e = hipMemcpy(t->dev, blob, nbytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (t->dev) (void)hipFree(t->dev);
+        delete t;
+        return fail(MCBS_EHIP, "topology upload failed: %s", hipGetErrorString(e));
+    }
+    *out = t;
+    return MCBS_OK;
+}
+
+extern "C" void mcbs_topology_destroy(mcbs_topology* t) {
+    if (!t) return;
+    if (t->dev) { (void)hipSetDevice(t->device); (void)hipFree(t->dev); }
+    delete t;
+}
+
+// ------------------------------------------------------------------ batch
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+extern "C" int mcbs_batch_create(const mcbs_topology* topo, const mcbs_batch_cfg* cfg, mcbs_batch** out) {
+    if (!topo || !cfg || !out) return fail(MCBS_EINVAL, "null argument");
+    if (cfg->abi_version != MCBS_ABI_VERSION) return fail(MCBS_EINVAL, "cfg ABI version %u, library %u", cfg->abi_version, MCBS_ABI_VERSION);
+    const mcbs_topo_header* h = topo->H();
+    if (cfg->n_envs == 0) return fail(MCBS_EINVAL, "n_envs must be positive");
+    if (cfg->device != topo->device) return fail(MCBS_EINVAL, "batch and topology are on different devices");
+    // CyberBattleEnv.validate_environment (cyberbattle_env.py:416-435)
+    if (h->n_nodes > cfg->maximum_node_count)
+        return fail(MCBS_EINVAL, "Network node count (%u) exceeds the specified limit of %u.", h->n_nodes, cfg->maximum_node_count);
+    if (cfg->maximum_node_count > MCBS_MAX_NODES) return fail(MCBS_ELIMIT, "maximum_node_count %u > %d", cfg->maximum_node_count, MCBS_MAX_NODES);
+    if (h->max_leak_per_action > cfg->maximum_discoverable_credentials_per_action)
+        return fail(MCBS_EINVAL, "Some action in the environment returns %u credentials which exceeds the maximum number of discoverable credentials of %u",
+                    h->max_leak_per_action, cfg->maximum_discoverable_credentials_per_action);
+    if (cfg->maximum_total_credentials == 0 || cfg->maximum_total_credentials > 65535u) return fail(MCBS_ELIMIT, "maximum_total_credentials out of range");
+    if (h->n_triples > cfg->maximum_total_credentials)
+        return fail(MCBS_ELIMIT, "the topology can leak %u distinct credentials but maximum_total_credentials is %u "
+                    "(the reference would overflow its observation space)", h->n_triples, cfg->maximum_total_credentials);
+    if (cfg->maximum_discoverable_credentials_per_action > 1023u) return fail(MCBS_ELIMIT, "maximum_discoverable_credentials_per_action too large");
+    if (cfg->defender_kind > MCBS_DEFENDER_SCAN_AND_REIMAGE) return fail(MCBS_EINVAL, "unknown defender kind");
+    if (cfg->defender_kind == MCBS_DEFENDER_SCAN_AND_REIMAGE && cfg->scan_frequency == 0) return fail(MCBS_EINVAL, "scan_frequency must be positive");
+    if (cfg->rng_kind > MCBS_RNG_TAPE) return fail(MCBS_EINVAL, "unknown rng kind");
+
+    mcbs_batch* b = new (std::nothrow) mcbs_batch();
+    if (!b) return fail(MCBS_ENOMEM, "out of memory");
+    b->topo = topo;
+    b->cfg = *cfg;
+    const uint32_t E = cfg->n_envs, N = h->n_nodes;
+    DevState& S = b->S;
+    S.E = E; S.N = N; S.NW = (N + 63) / 64;
+    S.SW = (h->n_cred_strings + 63) / 64; if (!S.SW) S.SW = 1;
+    S.TW = (h->n_triples + 63) / 64; if (!S.TW) S.TW = 1;
+    S.Cmax = cfg->maximum_total_credentials;
+    S.off_disc = 32u * N;
+    S.off_cred = (uint32_t)align_up(S.off_disc + N, 2);
+    S.body_stride = (uint32_t)align_up((size_t)S.off_cred + 2u * h->n_triples + 2u, 16);
+
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t o_h0 = take(16ull * E), o_h1 = take(16ull * E), o_ep = take(4ull * E), o_pend = take(8ull * E);
+    const size_t o_disc = take(8ull * S.NW * E), o_inst = take(8ull * S.NW * E), o_ever = take(8ull * S.NW * E),
+                 o_run = take(8ull * S.NW * E), o_priv = take(8ull * S.NW * E);
+    const size_t o_gath = take(8ull * S.SW * E), o_cach = take(8ull * S.TW * E);
+    const size_t o_init = take(S.body_stride);
+    const size_t o_digest = take(sizeof(ObsDigest) * (size_t)E);
+    const size_t o_body = take((size_t)S.body_stride * E);
+    b->arena_bytes = off;
+
+    hipError_t e = hipSetDevice(cfg->device);
+    if (e == hipSuccess) e = hipMalloc(&b->arena, b->arena_bytes);
+    if (e != hipSuccess) { delete b; return fail(MCBS_EHIP, "state allocation of %zu bytes failed: %s", off, hipGetErrorString(e)); }
+    uint8_t* a = b->arena;
+    S.h0 = reinterpret_cast<uint4*>(a + o_h0); S.h1 = reinterpret_cast<double2*>(a + o_h1);
+    S.episode = reinterpret_cast<uint32_t*>(a + o_ep); S.pending = reinterpret_cast<double*>(a + o_pend);
+    S.m_disc = reinterpret_cast<uint64_t*>(a + o_disc); S.m_inst = reinterpret_cast<uint64_t*>(a + o_inst);
+    S.m_ever = reinterpret_cast<uint64_t*>(a + o_ever); S.m_run = reinterpret_cast<uint64_t*>(a + o_run);
+    S.m_priv = reinterpret_cast<uint64_t*>(a + o_priv); S.m_gath = reinterpret_cast<uint64_t*>(a + o_gath);
+    S.m_cach = reinterpret_cast<uint64_t*>(a + o_cach);
+    S.body = a + o_body; S.init_body = a + o_init;
+    b->digest = reinterpret_cast<ObsDigest*>(a + o_digest);
+    b->T.base = topo->dev;
+
+    // reset image of one env body: rows of the initially owned nodes know all their properties and carry
+    // max(initial privilege, LocalUser) (actions.py:149-152,263-270); every row carries its literal tags
+    std::vector<uint8_t> init(S.body_stride, 0);
+    const mcbs_node_static* ns = reinterpret_cast<const mcbs_node_static*>(topo->host.data() + h->off_node);
+    for (uint32_t n = 0; n < N; ++n) {
+        Row r{};
+        const bool owned0 = (ns[n].flags & MCBS_NODE_INSTALLED0) != 0;
+        r.props = owned0 ? ns[n].props : 0;
+        r.misc = (owned0 ? ns[n].priv0 : 0u) | ((uint32_t)ns[n].tags0 << 8);
+        memcpy(init.data() + 32u * n, &r, sizeof(r));
+    }
+    memcpy(init.data() + S.off_disc, topo->host.data() + h->off_init_order, h->n_init_owned);
+    e = hipMemcpy(a + o_init, init.data(), init.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(b->arena); delete b; return fail(MCBS_EHIP, "init image upload failed: %s", hipGetErrorString(e)); }
+
+    StepCfg& C = b->C;
+    C.goal_reward = cfg->goal_reward; C.goal_low_availability = cfg->goal_low_availability;
+    C.goal_own_atleast_percent = cfg->goal_own_atleast_percent; C.maintain_sla = cfg->maintain_sla;
+    C.winning_reward = cfg->winning_reward; C.losing_reward = cfg->losing_reward; C.scan_probability = cfg->scan_probability;
+    C.total_sla_weight = h->total_sla_weight; C.full_availability = h->full_availability; C.full_sum = h->full_sum;
+    C.seed = cfg->seed; C.env_id_base = cfg->env_id_base;
+    C.has_attacker_goal = cfg->has_attacker_goal; C.goal_own_atleast = cfg->goal_own_atleast;
+    C.defender_goal_eviction = cfg->defender_goal_eviction; C.defender_kind = cfg->defender_kind;
+    C.scan_capacity = cfg->scan_capacity; C.scan_frequency = cfg->scan_frequency ? cfg->scan_frequency : 1;
+    C.auto_reset = cfg->auto_reset; C.max_episode_steps = cfg->max_episode_steps; C.rng_kind = cfg->rng_kind;
+    C.avail_any_order = h->avail_any_order;
+    C.L = h->n_local; C.R = h->n_remote; C.P = h->n_ports; C.V = h->max_slots; C.n_props = h->n_props;
+    C.K = cfg->maximum_discoverable_credentials_per_action;
+    C.off_node = h->off_node; C.off_slot_of = h->off_slot_of; C.off_slot = h->off_slot; C.off_payload = h->off_payload;
+    C.off_service = h->off_service; C.off_allowed = h->off_allowed; C.off_triple = h->off_triple;
+
+    hipLaunchKernelGGL(reset_kernel, dim3((E + 127) / 128), dim3(128), 0, 0, S, b->T, (const uint8_t*)nullptr, 0);
+    e = hipDeviceSynchronize();
+    if (e != hipSuccess) { (void)hipFree(b->arena); delete b; return fail(MCBS_EHIP, "initial reset failed: %s", hipGetErrorString(e)); }
+    *out = b;
+    return MCBS_OK;
+}
+
+extern "C" void mcbs_batch_destroy(mcbs_batch* b) {
+    if (!b) return;
+    (void)hipSetDevice(b->cfg.device);
+    for (hipEvent_t ev : b->ev) (void)hipEventDestroy(ev);
+    if (b->arena) (void)hipFree(b->arena);
+    delete b;
+}
+
+static int launch_ok(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MCBS_EHIP, "%s launch failed: %s", what, hipGetErrorString(e));
+    return MCBS_OK;
+}
+
+extern "C" int mcbs_reset(mcbs_batch* b, const uint8_t* env_mask, void* stream) {
+    if (!b) return fail(MCBS_EINVAL, "null batch");
+    hipLaunchKernelGGL(reset_kernel, dim3((b->S.E + 127) / 128), dim3(128), 0, (hipStream_t)stream, b->S, b->T, env_mask, 1);
+    return launch_ok("reset");
+}
+
+extern "C" int mcbs_set_draw_tape(mcbs_batch* b, const double* tape, uint32_t draws_per_step) {
+    if (!b) return fail(MCBS_EINVAL, "null batch");
+    b->tape = tape;
+    b->tape_dps = tape ? draws_per_step : 0;
+    return MCBS_OK;
+}
+
+static StepIO make_io(mcbs_batch* b, const int32_t* actions, float* reward, uint8_t* terminated, const mcbs_info_buffers* info) {
+    StepIO io{};
+    io.actions = actions; io.reward = reward; io.terminated = terminated;
+    if (info) {
+        io.availability = info->network_availability; io.step_count = info->step_count; io.truncated = info->truncated;
+        io.oob = info->out_of_bound; io.raw_reward = info->raw_reward;
+    }
+    io.tape = b->tape; io.tape_dps = b->tape_dps;
+    return io;
+}
+
+static int timing_begin(mcbs_batch* b, hipStream_t st, size_t* slot) {
+    *slot = (size_t)-1;
+    if (!b->timing) return MCBS_OK;
+    if (b->ev_used + 2 > b->ev.size()) {
+        for (int i = 0; i < 2; ++i) { hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); b->ev.push_back(ev); }
+    }
+    *slot = b->ev_used;
+    b->ev_used += 2;
+    HIP_TRY(hipEventRecord(b->ev[*slot], st));
+    return MCBS_OK;
+}
+
+static int timing_end(mcbs_batch* b, hipStream_t st, size_t slot) {
+    if (slot == (size_t)-1) return MCBS_OK;
+    HIP_TRY(hipEventRecord(b->ev[slot + 1], st));
+    return MCBS_OK;
+}
+
+extern "C" int mcbs_step(mcbs_batch* b, const int32_t* actions, float* reward, uint8_t* terminated,
+                         const mcbs_info_buffers* info, void* stream) {
+    if (!b || !actions || !reward || !terminated) return fail(MCBS_EINVAL, "null argument");
+    if (b->cfg.rng_kind == MCBS_RNG_TAPE && b->cfg.defender_kind != MCBS_DEFENDER_NONE && !b->tape)
+        return fail(MCBS_ESTATE, "rng_kind is TAPE but no draw tape was set (mcbs_set_draw_tape)");
+    hipStream_t st = (hipStream_t)stream;
+    const StepIO io = make_io(b, actions, reward, terminated, info);
+    size_t slot;
+    int rc = timing_begin(b, st, &slot);
+    if (rc) return rc;
+    hipLaunchKernelGGL(step_kernel<0>, dim3((b->S.E + 127) / 128), dim3(128), 0, st, b->S, b->T, b->C, io);
+    if ((rc = launch_ok("step"))) return rc;
+    return timing_end(b, st, slot);
+}
+
+static int launch_masks(mcbs_batch* b, const mcbs_obs_buffers* o, hipStream_t st);
+
+static int launch_obs(mcbs_batch* b, const mcbs_obs_buffers* o, hipStream_t st) {
+    ObsIO O{};
+    O.scalars = o->scalars; O.leaked = o->leaked_credentials; O.cache_matrix = o->credential_cache_matrix;
+    O.props = o->discovered_nodes_properties; O.priv = o->nodes_privilegelevel; O.mask_local = o->mask_local;
+    O.mask_remote = o->mask_remote; O.mask_connect = o->mask_connect; O.mask_discrete = o->mask_discrete;
+    O.Nmax = b->cfg.maximum_node_count; O.Cmax = b->cfg.maximum_total_credentials; O.K = b->cfg.maximum_discoverable_credentials_per_action;
+    hipLaunchKernelGGL(obs_small_kernel, dim3((b->S.E + 3) / 4), dim3(256), 0, st, b->S, b->T, b->C, O, b->digest);
+    int rc = launch_ok("obs_small");
+    if (rc) return rc;
+    return launch_masks(b, o, st);
+}
+
+template <int REGION>
+static int launch_region(mcbs_batch* b, int8_t* dst, size_t env_stride, size_t region_off, size_t len, hipStream_t st) {
+    const uint32_t Nm = b->cfg.maximum_node_count, Cm = b->cfg.maximum_total_credentials;
+    const uintptr_t base = reinterpret_cast<uintptr_t>(dst) + region_off;
+    int W = 1;
+    if (base % 16 == 0 && env_stride % 16 == 0 && len % 16 == 0) W = 16;
+    else if (base % 4 == 0 && env_stride % 4 == 0 && len % 4 == 0) W = 4;
+    const size_t chunks = (len + W - 1) / W;
+    const dim3 grid(b->S.E, (unsigned)((chunks + 255) / 256));
+    if (grid.y > 65535u) return fail(MCBS_ELIMIT, "mask region too large for one launch");
+    if (W == 16) hipLaunchKernelGGL((mask_kernel<16, REGION>), grid, dim3(256), 0, st, b->S, b->T, b->C, b->digest, dst, env_stride, region_off, Nm, Cm);
+    else if (W == 4) hipLaunchKernelGGL((mask_kernel<4, REGION>), grid, dim3(256), 0, st, b->S, b->T, b->C, b->digest, dst, env_stride, region_off, Nm, Cm);
+    else hipLaunchKernelGGL((mask_kernel<1, REGION>), grid, dim3(256), 0, st, b->S, b->T, b->C, b->digest, dst, env_stride, region_off, Nm, Cm);
+    return launch_ok("mask");
+}
+
+static int launch_masks(mcbs_batch* b, const mcbs_obs_buffers* o, hipStream_t st) {
+    const size_t Nm = b->cfg.maximum_node_count, Cm = b->cfg.maximum_total_credentials;
+    const size_t M = Nm * Nm * b->C.P * Cm, ML = Nm * b->C.L, MR = Nm * Nm * b->C.R;
+    int rc = MCBS_OK;
+    if (o->mask_connect && (rc = launch_region<0>(b, o->mask_connect, M, 0, M, st))) return rc;
+    if (o->mask_remote && (rc = launch_region<1>(b, o->mask_remote, MR, 0, MR, st))) return rc;
+    if (o->mask_discrete) {   // connect | local | remote (action_masking.py:96-110)
+        const size_t D = M + ML + MR;
+        if ((rc = launch_region<0>(b, o->mask_discrete, D, 0, M, st))) return rc;
+        if ((rc = launch_region<2>(b, o->mask_discrete, D, M, ML, st))) return rc;
+        if ((rc = launch_region<1>(b, o->mask_discrete, D, M + ML, MR, st))) return rc;
+    }
+    return rc;
+}
+
+extern "C" int mcbs_observe(mcbs_batch* b, const mcbs_obs_buffers* obs, void* stream) {
+    if (!b || !obs) return fail(MCBS_EINVAL, "null argument");
+    return launch_obs(b, obs, (hipStream_t)stream);
+}
+
+extern "C" int mcbs_step_observe(mcbs_batch* b, const int32_t* actions, float* reward, uint8_t* terminated,
+                                 const mcbs_info_buffers* info, const mcbs_obs_buffers* obs, void* stream) {
+    if (!b || !actions || !reward || !terminated || !obs) return fail(MCBS_EINVAL, "null argument");
+    if (b->cfg.rng_kind == MCBS_RNG_TAPE && b->cfg.defender_kind != MCBS_DEFENDER_NONE && !b->tape)
+        return fail(MCBS_ESTATE, "rng_kind is TAPE but no draw tape was set (mcbs_set_draw_tape)");
+    hipStream_t st = (hipStream_t)stream;
+    const StepIO io = make_io(b, actions, reward, terminated, info);
+    const dim3 grid((b->S.E + 127) / 128), block(128);
+    hipLaunchKernelGGL(step_kernel<1>, grid, block, 0, st, b->S, b->T, b->C, io);
+    int rc = launch_ok("step (attacker phase)");
+    if (rc) return rc;
+    if ((rc = launch_obs(b, obs, st))) return rc;
+    hipLaunchKernelGGL(step_kernel<2>, grid, block, 0, st, b->S, b->T, b->C, io);
+    return launch_ok("step (defender phase)");
+}
+
+extern "C" int mcbs_step_info(mcbs_batch* b, const mcbs_info_buffers* info, void* stream) {
+    if (!b || !info) return fail(MCBS_EINVAL, "null argument");
+    StepIO io = make_io(b, nullptr, nullptr, nullptr, info);
+    hipLaunchKernelGGL(info_kernel, dim3((b->S.E + 255) / 256), dim3(256), 0, (hipStream_t)stream, b->S, io);
+    return launch_ok("info");
+}
+
+extern "C" int mcbs_sample_actions(mcbs_batch* b, int32_t valid, uint64_t seed, uint64_t step, int32_t* actions_out, void* stream) {
+    if (!b || !actions_out) return fail(MCBS_EINVAL, "null argument");
+    hipLaunchKernelGGL(sample_kernel, dim3((b->S.E + 127) / 128), dim3(128), 0, (hipStream_t)stream, b->S, b->T, b->C, (int)valid, seed, step,
+                       b->cfg.maximum_node_count, b->cfg.maximum_total_credentials, actions_out);
+    return launch_ok("sample");
+}
+
+// ------------------------------------------------------------------ state export / import (debug, synchronous)
+extern "C" size_t mcbs_state_record_bytes(const mcbs_batch* b) {
+    if (!b) return 0;
+    const size_t n = sizeof(mcbs_state_header) + sizeof(mcbs_state_node) * b->S.N + 2ull * b->S.N + 2ull * b->cfg.maximum_total_credentials;
+    return align_up(n, 16);
+}
+
+extern "C" int mcbs_get_state(mcbs_batch* b, void* host_buf, size_t nbytes) {
+    if (!b || !host_buf) return fail(MCBS_EINVAL, "null argument");
+    const size_t rb = mcbs_state_record_bytes(b);
+    const DevState& S = b->S;
+    if (nbytes < rb * S.E) return fail(MCBS_EINVAL, "state buffer too small: need %zu bytes", rb * S.E);
+    HIP_TRY(hipSetDevice(b->cfg.device));
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<uint8_t> host(b->arena_bytes);
+    HIP_TRY(hipMemcpy(host.data(), b->arena, b->arena_bytes, hipMemcpyDeviceToHost));
+    auto at = [&](const void* devptr) { return host.data() + (static_cast<const uint8_t*>(devptr) - b->arena); };
+    const uint4* h0 = reinterpret_cast<const uint4*>(at(S.h0));
+    const double2* h1 = reinterpret_cast<const double2*>(at(S.h1));
+    const uint32_t* ep = reinterpret_cast<const uint32_t*>(at(S.episode));
+    const uint64_t* md = reinterpret_cast<const uint64_t*>(at(S.m_disc)), *mi = reinterpret_cast<const uint64_t*>(at(S.m_inst)),
+                   *me = reinterpret_cast<const uint64_t*>(at(S.m_ever)), *mr = reinterpret_cast<const uint64_t*>(at(S.m_run));
+    const uint8_t* body = at(S.body);
+    memset(host_buf, 0, rb * S.E);
+    for (uint32_t e = 0; e < S.E; ++e) {
+        uint8_t* p = static_cast<uint8_t*>(host_buf) + rb * e;
+        mcbs_state_header* sh = reinterpret_cast<mcbs_state_header*>(p);
+        const uint32_t flags = h0[e].y;
+        sh->step_count = h0[e].x; sh->done = flags & F_DONE ? 1 : 0; sh->truncated = flags & F_TRUNC ? 1 : 0; sh->episode = ep[e];
+        sh->n_discovered = h0[e].z & 0xFFFFu; sh->n_creds = h0[e].z >> 16;
+        sh->last_outcome_kind = (flags >> F_KIND_SHIFT) & 0xFu; sh->last_escalation = (flags >> F_LEVEL_SHIFT) & 3u;
+        sh->last_new_nodes = (flags >> F_NEWNODES_SHIFT) & 0x3FFu; sh->last_new_creds = (flags >> F_NEWCREDS_SHIFT) & 0x3FFu;
+        sh->last_oob = flags & F_OOB ? 1 : 0;
+        sh->cum_reward = h1[e].x; sh->availability = h1[e].y;
+        mcbs_state_node* sn = reinterpret_cast<mcbs_state_node*>(p + sizeof(mcbs_state_header));
+        const uint8_t* eb = body + (size_t)e * S.body_stride;
+        for (uint32_t n = 0; n < S.N; ++n) {
+            Row r;
+            memcpy(&r, eb + 32u * n, sizeof(r));
+            const size_t k = (size_t)(n >> 6) * S.E + e;
+            const uint64_t bit = 1ull << (n & 63u);
+            sn[n].discovered_props = r.props; sn[n].attacked_ever = r.ever; sn[n].attacked_since = r.since;
+            sn[n].discovered = (md[k] & bit) != 0; sn[n].installed = (mi[k] & bit) != 0; sn[n].ever_owned = (me[k] & bit) != 0;
+            sn[n].running = (mr[k] & bit) != 0;
+            sn[n].privilege = (uint8_t)(r.misc & 0xFFu); sn[n].tags = (uint8_t)((r.misc >> 8) & 0xFFu);
+            sn[n].countdown = sn[n].running ? 0 : (uint8_t)((r.misc >> 16) & 0xFFu);
+        }
+        uint16_t* order = reinterpret_cast<uint16_t*>(p + sizeof(mcbs_state_header) + sizeof(mcbs_state_node) * S.N);
+        for (uint32_t k = 0; k < S.N; ++k) order[k] = k < sh->n_discovered ? eb[S.off_disc + k] : 0xFFFF;
+        uint16_t* cc = order + S.N;
+        const uint16_t* cl = reinterpret_cast<const uint16_t*>(eb + S.off_cred);
+        for (uint32_t k = 0; k < b->cfg.maximum_total_credentials; ++k) cc[k] = k < sh->n_creds ? cl[k] : 0xFFFF;
+    }
+    return MCBS_OK;
+}
+
+extern "C" int mcbs_set_state(mcbs_batch* b, const void* host_buf, size_t nbytes) {
+    (void)b; (void)host_buf; (void)nbytes;
+    return fail(MCBS_ESTATE, "mcbs_set_state is not implemented in this round");
+}
+
+// ------------------------------------------------------------------ timing
+extern "C" int mcbs_timing_enable(mcbs_batch* b, int32_t on) {
+    if (!b) return fail(MCBS_EINVAL, "null batch");
+    b->timing = on != 0;
+    b->ev_used = 0; b->timed_ms = 0.0; b->timed_launches = 0;
+    return MCBS_OK;
+}
+
+extern "C" int mcbs_timing_read(mcbs_batch* b, double* total_ms, uint64_t* launches) {
+    if (!b) return fail(MCBS_EINVAL, "null batch");
+    for (size_t i = 0; i + 1 < b->ev_used; i += 2) {
+        HIP_TRY(hipEventSynchronize(b->ev[i + 1]));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, b->ev[i], b->ev[i + 1]));
+        b->timed_ms += ms;
+        b->timed_launches += 1;
+    }
+    b->ev_used = 0;
+    if (total_ms) *total_ms = b->timed_ms;
+    if (launches) *launches = b->timed_launches;
+    return MCBS_OK;
+}

@@ -1,0 +1,133 @@
+// mcbs_device.h — device-side state layout and topology accessors of the MI355X step engine.
+//
+// Data layout in HBM (DESIGN.md "State layout"):
+//   * header columns, structure-of-arrays with the ENV index fastest, so that lane i of a wavefront
+//     (= env base+i) reads consecutive addresses: one 16-byte uint4 {step_count, flags, counts, aux}
+//     and one double2 {cum_reward, availability} per env, plus u64 bit-mask columns [word][env] for the
+//     node sets (discovered / agent installed / ever owned / running / privilege>=LocalUser) and for the
+//     gathered-credential and cached-triple sets;
+//   * one "body" record per env (array-of-structures, stride body_stride): 32-byte node rows
+//     (discovered-property mask, attacked-ever / attacked-since-reimage slot masks, privilege, tags,
+//     re-imaging countdown) followed by the discovery order (u8 node ids) and the credential cache
+//     (u16 triple ids).  Rows are gathered by node id, which differs per env, so they sit next to each
+//     other per env rather than along the env axis.
+//   * the topology blob (include/mcbs.h "MCBT") is shared by every env and read-only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "mcbs.h"
+
+namespace mcbs {
+
+// flags word (h0.y)
+constexpr uint32_t F_DONE = 1u, F_TRUNC = 2u, F_OOB = 4u;
+constexpr int F_KIND_SHIFT = 4;      // 4 bits  last outcome kind (MCBS_OUT_*)
+constexpr int F_LEVEL_SHIFT = 8;     // 2 bits  last escalation level
+constexpr int F_NEWNODES_SHIFT = 12; // 10 bits newly discovered nodes of the last action
+constexpr int F_NEWCREDS_SHIFT = 22; // 10 bits credentials newly added to the cache by the last action
+
+struct Row {            // 32 bytes
+    uint64_t props;     // discovered properties
+    uint32_t ever;      // slot s exploited at least once            (actions.py:396-407)
+    uint32_t since;     // ... and not re-imaged since
+    uint32_t misc;      // privilege | tags << 8 | countdown << 16
+    uint32_t spare[3];
+};
+static_assert(sizeof(Row) == 32, "row");
+
+struct DevState {
+    uint4*    h0;       // [E] {step_count, flags, n_discovered | n_creds << 16, owned_count | imaging_count << 16}
+    double2*  h1;       // [E] {cum_reward, availability}
+    uint32_t* episode;  // [E]
+    double*   pending;  // [E] raw reward carried between the split phases of mcbs_step_observe
+    uint64_t* m_disc;   // [NW][E]
+    uint64_t* m_inst;
+    uint64_t* m_ever;
+    uint64_t* m_run;
+    uint64_t* m_priv;
+    uint64_t* m_gath;   // [SW][E]
+    uint64_t* m_cach;   // [TW][E]
+    uint8_t*  body;     // [E][body_stride]
+    const uint8_t* init_body; // [body_stride] image of a freshly reset env
+    uint32_t E, N, NW, SW, TW;
+    uint32_t body_stride, off_disc, off_cred, Cmax;
+};
+
+struct Topo {           // device view of the MCBT blob
+    const uint8_t* base;
+    __device__ __forceinline__ const mcbs_topo_header& H() const { return *reinterpret_cast<const mcbs_topo_header*>(base); }
+};
+
+struct StepCfg {        // the parts of mcbs_batch_cfg the kernels read
+    double goal_reward, goal_low_availability, goal_own_atleast_percent;
+    double maintain_sla, winning_reward, losing_reward, scan_probability;
+    double total_sla_weight, full_availability, full_sum;
+    uint64_t seed, env_id_base;
+    uint32_t has_attacker_goal, goal_own_atleast, defender_goal_eviction, defender_kind;
+    uint32_t scan_capacity, scan_frequency, auto_reset, max_episode_steps, rng_kind, avail_any_order;
+    uint32_t L, R, P, V, n_props, K;
+    // section offsets into the blob, hoisted so kernels do not chase the header
+    uint32_t off_node, off_slot_of, off_slot, off_payload, off_service, off_allowed, off_triple;
+};
+
+struct StepIO {
+    const int32_t* actions;
+    float* reward;
+    uint8_t* terminated;
+    double* availability;
+    int32_t* step_count;
+    uint8_t* truncated;
+    uint8_t* oob;
+    float* raw_reward;
+    const double* tape;
+    uint32_t tape_dps;
+};
+
+struct ObsIO {
+    int32_t* scalars; int32_t* leaked; int32_t* cache_matrix; int32_t* props; int32_t* priv;
+    int8_t* mask_local; int8_t* mask_remote; int8_t* mask_connect; int8_t* mask_discrete;
+    uint32_t Nmax, Cmax, K;
+};
+
+// ------------------------------ Philox4x32-10 (Random123) ------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ double to_double53(uint32_t a, uint32_t b) {
+    return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0;
+}
+
+// Header + mask columns of a freshly reset env (cyberbattle_env.py:375-394, actions.py:149-152): the nodes with
+// agent_installed are owned at max(initial privilege, LocalUser), discovered in network order, every node Running,
+// no credential gathered, availability 1.0.  The body (rows, discovery order) is copied from init_body by the caller.
+__device__ __forceinline__ void reset_header(const DevState& S, const Topo& T, uint32_t e, uint32_t episode) {
+    const mcbs_topo_header& H = T.H();
+    const uint8_t* order = T.base + H.off_init_order;
+    const uint32_t n_init = H.n_init_owned;
+    for (uint32_t w = 0; w < S.NW; ++w) {
+        uint64_t m = 0;
+        for (uint32_t i = 0; i < n_init; ++i) { const uint32_t n = order[i]; if ((n >> 6) == w) m |= 1ull << (n & 63u); }
+        const uint32_t rem = S.N - w * 64u;
+        const size_t k = (size_t)w * S.E + e;
+        S.m_disc[k] = m; S.m_inst[k] = m; S.m_ever[k] = m; S.m_priv[k] = m;
+        S.m_run[k] = rem >= 64u ? ~0ull : ((1ull << rem) - 1ull);
+    }
+    for (uint32_t w = 0; w < S.SW; ++w) S.m_gath[(size_t)w * S.E + e] = 0;
+    for (uint32_t w = 0; w < S.TW; ++w) S.m_cach[(size_t)w * S.E + e] = 0;
+    S.h0[e] = make_uint4(0u, 0u, n_init, n_init);
+    S.h1[e] = make_double2(0.0, 1.0);
+    S.episode[e] = episode;
+    S.pending[e] = 0.0;
+}
+
+} // namespace mcbs

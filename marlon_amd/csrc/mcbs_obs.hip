@@ -1,0 +1,189 @@
+// mcbs_obs.hip — observation and action-mask kernels (gfx950).
+//
+// Writes what CyberBattleEnv.__observation_reward_from_action_result / __get_blank_observation /
+// __update_action_mask assemble (cyberbattle_env.py:859-933, 753-773, 643-677) directly in the flat layout
+// AttackerEnvWrapper.transform_observation hands to Stable-Baselines3 (attack_wrapper.py:474-522) and, for
+// mask_discrete, in the order of MaskedDiscreteAttackerWrapper.action_masks (action_masking.py:96-110:
+// connect, local, remote).  Pure streaming stores: the state read per env is a few hundred bytes, the
+// output up to N*N*P*C bytes, so this tier is bound by HBM write bandwidth.
+//
+//   obs_small_kernel : ONE WAVEFRONT PER ENV.  The 64 lanes load the env's discovery order together, build the
+//                      node -> external-index map in LDS, ballot the "source is owned" bits, and stream out the
+//                      small fields with lane-strided (coalesced) stores.  It also leaves a 64-byte digest per
+//                      env (owned-source bits, counts, blank flag) for the mask kernel.
+//   mask_kernel      : one thread per W output bytes of a mask region (W = 16 when the per-env size allows
+//                      16-byte stores, else 4 or 1); reads only the digest.
+#pragma once
+#include "mcbs_device.h"
+
+namespace mcbs {
+
+struct ObsDigest {          // 64 bytes per env
+    uint64_t own_ext[4];    // bit i: the node at external index i has the agent installed
+    uint32_t n_disc, n_creds, blank, pad;
+    uint32_t pad2[4];
+};
+static_assert(sizeof(ObsDigest) == 64, "digest");
+
+__global__ __launch_bounds__(256) void obs_small_kernel(DevState S, Topo T, StepCfg C, ObsIO O, ObsDigest* digest) {
+    __shared__ uint8_t ext_of_all[4][256];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t e = blockIdx.x * 4u + wave;
+    if (e >= S.E) return;                     // whole wavefront leaves together
+    uint8_t* ext_of = ext_of_all[wave];
+    const uint4 h0 = S.h0[e];
+    const uint32_t flags = h0.y, n_disc = h0.z & 0xFFFFu, n_creds = h0.z >> 16;
+    const bool blank = (flags & F_OOB) != 0;
+    const uint32_t kind = (flags >> F_KIND_SHIFT) & 0xFu, level = (flags >> F_LEVEL_SHIFT) & 3u;
+    const uint32_t new_nodes = (flags >> F_NEWNODES_SHIFT) & 0x3FFu, new_creds = (flags >> F_NEWCREDS_SHIFT) & 0x3FFu;
+    const uint8_t* body = S.body + (size_t)e * S.body_stride;
+    const Row* rows = reinterpret_cast<const Row*>(body);
+    const uint8_t* dl = body + S.off_disc;
+    const uint16_t* cl = reinterpret_cast<const uint16_t*>(body + S.off_cred);
+    const mcbs_node_static* NS = reinterpret_cast<const mcbs_node_static*>(T.base + C.off_node);
+    const mcbs_triple* TR = reinterpret_cast<const mcbs_triple*>(T.base + C.off_triple);
+    const uint32_t Nm = O.Nmax, NP = C.n_props, L = C.L;
+
+    uint64_t own_ext[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (uint32_t c = 0; c < 4; ++c) {
+        const uint32_t i = c * 64u + lane;
+        bool own = false;
+        if (c * 64u < n_disc) {               // wave-uniform
+            if (i < n_disc) {
+                const uint32_t n = dl[i];
+                ext_of[n] = (uint8_t)i;
+                own = (S.m_inst[(size_t)(n >> 6) * S.E + e] >> (n & 63u)) & 1ull;
+            }
+            own_ext[c] = __ballot(own);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+
+    if (lane == 0) {
+        ObsDigest d;
+        for (int c = 0; c < 4; ++c) d.own_ext[c] = blank ? 0ull : own_ext[c];
+        d.n_disc = n_disc; d.n_creds = n_creds; d.blank = blank ? 1u : 0u; d.pad = 0;
+        d.pad2[0] = d.pad2[1] = d.pad2[2] = d.pad2[3] = 0;
+        digest[e] = d;
+    }
+
+    if (O.scalars && lane < 7) {
+        int32_t v = 0;
+        if (lane == 6) v = (int32_t)n_disc;
+        else if (!blank) {
+            if (lane == 0) v = (kind == MCBS_OUT_LEAKED_NODES || kind == MCBS_OUT_LEAKED_CREDENTIALS) ? (int32_t)new_nodes : 0;
+            else if (lane == 1) v = kind == MCBS_OUT_LATERAL_MOVE;
+            else if (lane == 2) v = kind == MCBS_OUT_CUSTOMER_DATA;
+            else if (lane == 3) v = kind == MCBS_OUT_PROBE_SUCCEEDED ? 2 : (kind == MCBS_OUT_PROBE_FAILED ? 1 : 0);
+            else if (lane == 4) v = kind == MCBS_OUT_PRIVILEGE_ESCALATION ? (int32_t)level : 0;
+            else v = (int32_t)n_creds;
+        }
+        O.scalars[(size_t)e * 7 + lane] = v;
+    }
+    if (O.leaked) {
+        int32_t* out = O.leaked + (size_t)e * O.K * 4;
+        const bool have = !blank && kind == MCBS_OUT_LEAKED_CREDENTIALS;
+        for (uint32_t idx = lane; idx < O.K * 4u; idx += 64u) {
+            const uint32_t r = idx >> 2, c = idx & 3u;
+            int32_t v = 0;
+            if (have && r < new_creds) {
+                const uint32_t ci = n_creds - new_creds + r;
+                const mcbs_triple t = TR[cl[ci]];
+                v = c == 0 ? 1 : c == 1 ? (int32_t)ci : c == 2 ? (int32_t)ext_of[t.node] : (int32_t)t.port;
+            }
+            out[idx] = v;
+        }
+    }
+    if (O.cache_matrix) {
+        int32_t* out = O.cache_matrix + (size_t)e * O.Cmax * 2;
+        for (uint32_t idx = lane; idx < O.Cmax * 2u; idx += 64u) {
+            const uint32_t r = idx >> 1;
+            int32_t v = 0;
+            if (!blank && r < n_creds) {
+                const mcbs_triple t = TR[cl[r]];
+                v = (idx & 1u) ? (int32_t)t.port : (int32_t)ext_of[t.node];
+            }
+            out[idx] = v;
+        }
+    }
+    if (O.props) {
+        int32_t* out = O.props + (size_t)e * Nm * NP;
+        for (uint32_t i = 0; i < Nm; ++i) {   // one discovered node per iteration, lanes over properties
+            uint64_t pm = 0;
+            if (!blank && i < n_disc) pm = rows[dl[i]].props;
+            for (uint32_t p = lane; p < NP; p += 64u) out[i * NP + p] = blank ? 2 : (int32_t)((pm >> p) & 1ull);
+        }
+    }
+    if (O.priv) {
+        int32_t* out = O.priv + (size_t)e * Nm;
+        for (uint32_t i = lane; i < Nm; i += 64u) out[i] = (!blank && i < n_disc) ? (int32_t)(rows[dl[i]].misc & 0xFFu) : 0;
+    }
+    if (O.mask_local) {
+        int8_t* out = O.mask_local + (size_t)e * Nm * L;
+        for (uint32_t idx = lane; idx < Nm * L; idx += 64u) {
+            const uint32_t i = idx / L, l = idx - i * L;
+            int8_t v = 0;
+            if (!blank && i < n_disc && ((own_ext[i >> 6] >> (i & 63u)) & 1ull)) v = (int8_t)((NS[dl[i]].local_mask >> l) & 1u);
+            out[idx] = v;
+        }
+    }
+}
+
+// REGION 0: connect [N,N,P,C]   1: remote [N,N,R]   2: local [N,L]
+template <int W, int REGION>
+__global__ __launch_bounds__(256) void mask_kernel(DevState S, Topo T, StepCfg C, const ObsDigest* digest, int8_t* dst,
+                                                   size_t env_stride, size_t region_off, uint32_t Nm, uint32_t Cm) {
+    const uint32_t e = blockIdx.x;
+    const uint32_t k = blockIdx.y * blockDim.x + threadIdx.x;
+    const uint32_t inner = REGION == 0 ? C.P * Cm : (REGION == 1 ? C.R : C.L);
+    const uint32_t len = REGION == 2 ? Nm * inner : Nm * Nm * inner;
+    const uint32_t idx0 = k * W;
+    if (idx0 >= len) return;
+    const ObsDigest d = digest[e];
+    uint32_t q = idx0 / inner, in = idx0 - q * inner;     // q = s*N + t (or s for local), in = position inside the row
+    uint32_t s, t;
+    if (REGION == 2) { s = q; t = 0; } else { s = q / Nm; t = q - s * Nm; }
+    const uint8_t* dl = S.body + (size_t)e * S.body_stride + S.off_disc;
+    const mcbs_node_static* NS = reinterpret_cast<const mcbs_node_static*>(T.base + C.off_node);
+    alignas(16) int8_t v[W];
+    uint32_t lmask = 0;
+    bool row_on = false;
+    auto load_row = [&]() {
+        row_on = s < Nm && ((d.own_ext[(s >> 6) & 3u] >> (s & 63u)) & 1ull) && (REGION == 2 || t < d.n_disc);
+        if (REGION == 2 && row_on) lmask = NS[dl[s]].local_mask;
+    };
+    load_row();
+    uint32_t c = REGION == 0 ? in % Cm : 0u;              // credential index inside the (source, target, port) row
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+        int8_t b = 0;
+        if (idx0 + j < len && row_on) {
+            if (REGION == 0) b = c < d.n_creds;
+            else if (REGION == 1) b = 1;
+            else b = (int8_t)((lmask >> in) & 1u);
+        }
+        v[j] = b;
+        if (REGION == 0 && ++c == Cm) c = 0;
+        if (++in == inner) {
+            in = 0;
+            if (REGION == 2) s += 1; else if (++t == Nm) { t = 0; s += 1; }
+            load_row();
+        }
+    }
+    int8_t* out = dst + (size_t)e * env_stride + region_off + idx0;
+    if (W == 16) *reinterpret_cast<uint4*>(out) = *reinterpret_cast<const uint4*>(v);
+    else if (W == 4) *reinterpret_cast<uint32_t*>(out) = *reinterpret_cast<const uint32_t*>(v);
+    else out[0] = v[0];
+}
+
+#define MCBS_INST(W) \
+    template __global__ void mask_kernel<W, 0>(DevState, Topo, StepCfg, const ObsDigest*, int8_t*, size_t, size_t, uint32_t, uint32_t); \
+    template __global__ void mask_kernel<W, 1>(DevState, Topo, StepCfg, const ObsDigest*, int8_t*, size_t, size_t, uint32_t, uint32_t); \
+    template __global__ void mask_kernel<W, 2>(DevState, Topo, StepCfg, const ObsDigest*, int8_t*, size_t, size_t, uint32_t, uint32_t);
+MCBS_INST(16)
+MCBS_INST(4)
+MCBS_INST(1)
+
+} // namespace mcbs

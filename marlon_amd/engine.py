@@ -1,0 +1,235 @@
+"""ctypes binding of libmcbs.so (include/mcbs.h) over PyTorch-ROCm tensors.
+
+PyTorch is plumbing here (device memory, streams); every computation is done by the HIP kernels
+behind the C ABI.  There is NO CPU fallback: if the native library is missing or a call fails,
+this module raises.  The CPU oracle under oracle/ is test infrastructure and is never imported
+from here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Iterable, Optional
+
+import numpy as np
+
+from ._abi import BatchCfg, EnvSpec, InfoBuffers, ObsBuffers, split_state, state_record_bytes
+from .flatten import FlatTopology
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmcbs.so")
+
+EXPORTS = [
+    "mcbs_last_error", "mcbs_abi_version", "mcbs_topology_create", "mcbs_topology_destroy", "mcbs_batch_create",
+    "mcbs_batch_destroy", "mcbs_reset", "mcbs_step", "mcbs_step_observe", "mcbs_observe", "mcbs_step_info",
+    "mcbs_sample_actions", "mcbs_set_draw_tape", "mcbs_state_record_bytes", "mcbs_get_state", "mcbs_set_state",
+    "mcbs_timing_enable", "mcbs_timing_read",
+]
+
+_lib = None
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+class McbsError(RuntimeError):
+    pass
+
+
+def load_library(path: Optional[str] = None):
+    """Load libmcbs.so; raise loudly when it is absent (run `python -c 'import __graft_entry__ as g; g.build()'`)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise NativeLibraryMissing(
+            f"{p} not found: the HIP extension has not been built. Build it with `make -C marlon_amd/csrc` "
+            f"(hipcc, gfx950). There is no CPU fallback for the step engine.")
+    lib = C.CDLL(p)
+    lib.mcbs_last_error.restype = C.c_char_p
+    lib.mcbs_abi_version.restype = C.c_uint32
+    lib.mcbs_topology_create.argtypes = [C.c_void_p, C.c_size_t, C.c_int32, C.POINTER(C.c_void_p)]
+    lib.mcbs_topology_destroy.argtypes = [C.c_void_p]
+    lib.mcbs_batch_create.argtypes = [C.c_void_p, C.POINTER(BatchCfg), C.POINTER(C.c_void_p)]
+    lib.mcbs_batch_destroy.argtypes = [C.c_void_p]
+    lib.mcbs_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.mcbs_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(InfoBuffers), C.c_void_p]
+    lib.mcbs_step_observe.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(InfoBuffers),
+                                      C.POINTER(ObsBuffers), C.c_void_p]
+    lib.mcbs_observe.argtypes = [C.c_void_p, C.POINTER(ObsBuffers), C.c_void_p]
+    lib.mcbs_step_info.argtypes = [C.c_void_p, C.POINTER(InfoBuffers), C.c_void_p]
+    lib.mcbs_sample_actions.argtypes = [C.c_void_p, C.c_int32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
+    lib.mcbs_set_draw_tape.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+    lib.mcbs_state_record_bytes.restype = C.c_size_t
+    lib.mcbs_state_record_bytes.argtypes = [C.c_void_p]
+    lib.mcbs_get_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.mcbs_set_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.mcbs_timing_enable.argtypes = [C.c_void_p, C.c_int32]
+    lib.mcbs_timing_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    for name in EXPORTS:
+        if not hasattr(lib, name):
+            raise NativeLibraryMissing(f"{p} does not export {name}")
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _check(lib, rc: int, what: str) -> None:
+    if rc != 0:
+        raise McbsError(f"{what} failed ({rc}): {lib.mcbs_last_error().decode(errors='replace')}")
+
+
+def obs_field_shapes(topo: FlatTopology, spec: EnvSpec) -> Dict[str, tuple]:
+    N, Cm, K = spec.maximum_node_count, spec.maximum_total_credentials, spec.maximum_discoverable_credentials_per_action
+    L, R, P = len(topo.local_vulnerabilities), len(topo.remote_vulnerabilities), len(topo.ports)
+    return {
+        "scalars": ((7,), "int32"), "leaked_credentials": ((K, 4), "int32"), "credential_cache_matrix": ((Cm, 2), "int32"),
+        "discovered_nodes_properties": ((N, len(topo.properties)), "int32"), "nodes_privilegelevel": ((N,), "int32"),
+        "mask_local": ((N, L), "int8"), "mask_remote": ((N, N, R), "int8"), "mask_connect": ((N, N, P, Cm), "int8"),
+        "mask_discrete": ((N * N * P * Cm + N * L + N * N * R,), "int8"),
+    }
+
+
+class BatchEngine:
+    """n_envs CyberBattleSim environments sharing one topology, advanced on one MI355X."""
+
+    def __init__(self, topo: FlatTopology, spec: EnvSpec, device: Optional[str] = None):
+        import torch
+
+        self.torch = torch
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise McbsError("no HIP device visible to PyTorch: the step engine needs a GPU (there is no CPU fallback)")
+        self.device = torch.device(device if device is not None else f"cuda:{spec.device}")
+        spec.device = self.device.index or 0
+        self.topo, self.spec = topo, spec
+        self.E = spec.n_envs
+        blob = np.frombuffer(topo.blob, dtype=np.uint8)
+        self._topo_h = C.c_void_p()
+        _check(self.lib, self.lib.mcbs_topology_create(blob.ctypes.data, blob.size, spec.device, C.byref(self._topo_h)), "mcbs_topology_create")
+        self._cfg = spec.to_cfg()
+        self._h = C.c_void_p()
+        rc = self.lib.mcbs_batch_create(self._topo_h, C.byref(self._cfg), C.byref(self._h))
+        if rc != 0:
+            msg = self.lib.mcbs_last_error().decode(errors="replace")
+            self.lib.mcbs_topology_destroy(self._topo_h)
+            self._topo_h = None
+            raise (ValueError if rc == -1 else McbsError)(f"mcbs_batch_create failed ({rc}): {msg}")
+        self._shapes = obs_field_shapes(topo, spec)
+        self._tape = None
+        f32, u8, f64, i32 = torch.float32, torch.uint8, torch.float64, torch.int32
+        dev = self.device
+        self.reward = torch.zeros(self.E, dtype=f32, device=dev)
+        self.terminated = torch.zeros(self.E, dtype=u8, device=dev)
+        self.info = dict(network_availability=torch.zeros(self.E, dtype=f64, device=dev),
+                         step_count=torch.zeros(self.E, dtype=i32, device=dev),
+                         truncated=torch.zeros(self.E, dtype=u8, device=dev),
+                         out_of_bound=torch.zeros(self.E, dtype=u8, device=dev),
+                         raw_reward=torch.zeros(self.E, dtype=f32, device=dev))
+        self._info_struct = InfoBuffers(**{k: v.data_ptr() for k, v in self.info.items()})
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self.torch.cuda.synchronize(self.device)
+            self.lib.mcbs_batch_destroy(self._h)
+            self._h = None
+        if getattr(self, "_topo_h", None):
+            self.lib.mcbs_topology_destroy(self._topo_h)
+            self._topo_h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- helpers --
+    def _stream(self) -> int:
+        return self.torch.cuda.current_stream(self.device).cuda_stream
+
+    def alloc_obs(self, fields: Optional[Iterable[str]] = None) -> dict:
+        t = self.torch
+        out = {}
+        for f in (fields or [k for k in self._shapes if k != "mask_discrete"]):
+            shape, dt = self._shapes[f]
+            out[f] = t.zeros((self.E,) + shape, dtype=getattr(t, dt), device=self.device)
+        return out
+
+    @staticmethod
+    def _obs_struct(obs: dict) -> ObsBuffers:
+        return ObsBuffers(**{k: v.data_ptr() for k, v in obs.items()})
+
+    def _actions(self, actions):
+        t = self.torch
+        a = actions if isinstance(actions, t.Tensor) else t.as_tensor(np.asarray(actions), device=self.device)
+        a = a.to(device=self.device, dtype=t.int32).contiguous()
+        if tuple(a.shape) != (self.E, 5):
+            raise ValueError(f"actions must have shape ({self.E}, 5), got {tuple(a.shape)}")
+        return a
+
+    # -- the C ABI --
+    def reset(self, env_mask=None) -> None:
+        ptr = None
+        if env_mask is not None:
+            env_mask = env_mask.to(device=self.device, dtype=self.torch.uint8).contiguous()
+            ptr = env_mask.data_ptr()
+        _check(self.lib, self.lib.mcbs_reset(self._h, ptr, self._stream()), "mcbs_reset")
+
+    def set_draw_tape(self, tape) -> None:
+        t = self.torch
+        if tape is None:
+            self._tape = None
+            _check(self.lib, self.lib.mcbs_set_draw_tape(self._h, None, 0), "mcbs_set_draw_tape")
+            return
+        tape = tape if isinstance(tape, t.Tensor) else t.as_tensor(np.asarray(tape, dtype=np.float64))
+        self._tape = tape.to(device=self.device, dtype=t.float64).reshape(self.E, -1).contiguous()
+        _check(self.lib, self.lib.mcbs_set_draw_tape(self._h, self._tape.data_ptr(), self._tape.shape[1]), "mcbs_set_draw_tape")
+
+    def step(self, actions, with_info: bool = True):
+        """One CyberBattleEnv.step for every env (observation excluded).  Returns (reward, terminated) device tensors,
+        overwritten by the next call; self.info holds StepInfo tensors when with_info."""
+        a = self._actions(actions)
+        _check(self.lib, self.lib.mcbs_step(self._h, a.data_ptr(), self.reward.data_ptr(), self.terminated.data_ptr(),
+                                            C.byref(self._info_struct) if with_info else None, self._stream()), "mcbs_step")
+        return self.reward, self.terminated
+
+    def step_observe(self, actions, obs: dict):
+        a = self._actions(actions)
+        b = self._obs_struct(obs)
+        _check(self.lib, self.lib.mcbs_step_observe(self._h, a.data_ptr(), self.reward.data_ptr(), self.terminated.data_ptr(),
+                                                    C.byref(self._info_struct), C.byref(b), self._stream()), "mcbs_step_observe")
+        return self.reward, self.terminated
+
+    def observe(self, obs: dict) -> dict:
+        b = self._obs_struct(obs)
+        _check(self.lib, self.lib.mcbs_observe(self._h, C.byref(b), self._stream()), "mcbs_observe")
+        return obs
+
+    def step_info(self) -> dict:
+        _check(self.lib, self.lib.mcbs_step_info(self._h, C.byref(self._info_struct), self._stream()), "mcbs_step_info")
+        return self.info
+
+    def sample_actions(self, valid: bool, seed: int, step: int, out=None):
+        t = self.torch
+        if out is None:
+            out = t.empty((self.E, 5), dtype=t.int32, device=self.device)
+        _check(self.lib, self.lib.mcbs_sample_actions(self._h, int(bool(valid)), int(seed), int(step), out.data_ptr(), self._stream()),
+               "mcbs_sample_actions")
+        return out
+
+    def get_state(self):
+        rb = state_record_bytes(self.topo.n_nodes, self.spec.maximum_total_credentials)
+        assert rb == self.lib.mcbs_state_record_bytes(self._h)
+        buf = np.zeros(rb * self.E, np.uint8)
+        _check(self.lib, self.lib.mcbs_get_state(self._h, buf.ctypes.data, buf.size), "mcbs_get_state")
+        return split_state(buf, self.E, self.topo.n_nodes, self.spec.maximum_total_credentials)
+
+    def timing_enable(self, on: bool = True) -> None:
+        _check(self.lib, self.lib.mcbs_timing_enable(self._h, int(on)), "mcbs_timing_enable")
+
+    def timing_read(self):
+        ms, n = C.c_double(), C.c_uint64()
+        _check(self.lib, self.lib.mcbs_timing_read(self._h, C.byref(ms), C.byref(n)), "mcbs_timing_read")
+        return ms.value, n.value

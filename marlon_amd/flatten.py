@@ -53,7 +53,7 @@ HEADER_DT = np.dtype([
     ("total_sla_weight", "<f8"), ("full_availability", "<f8"),
     ("off_node", "<u4"), ("off_slot_of", "<u4"), ("off_slot", "<u4"), ("off_payload", "<u4"),
     ("off_service", "<u4"), ("off_allowed", "<u4"), ("off_triple", "<u4"), ("off_code", "<u4"),
-    ("off_init_order", "<u4"), ("n_init_owned", "<u4"), ("reserved", "<u4", (14,)),
+    ("off_init_order", "<u4"), ("n_init_owned", "<u4"), ("full_sum", "<f8"), ("reserved", "<u4", (12,)),
 ])
 NODE_DT = np.dtype([
     ("props", "<u8"), ("sla_weight", "<f8"), ("avail_term", "<f8"), ("value", "<i4"),
@@ -379,7 +379,7 @@ def flatten(environment) -> FlatTopology:
     h["n_payload"], h["n_services"], h["n_allowed"], h["n_code"] = len(payload), len(services), len(allowed), len(code)
     h["max_leak_per_action"] = max_leak
     h["avail_any_order"] = any_order
-    h["total_sla_weight"], h["full_availability"] = total_weight, full_avail
+    h["total_sla_weight"], h["full_availability"], h["full_sum"] = total_weight, full_avail, float(full)
     h["n_init_owned"] = len(init_owned)
     blob = hdr.tobytes() + bytes(body)
 

@@ -562,7 +562,8 @@ void cbo_destroy(void* h) {
     free(o->env); free(o->blob); free(o);
 }
 
-void cbo_reset(void* h, int env) { oracle* o = (oracle*)h; int ep = o->env[env].episode; reset_env(o, &o->env[env]); o->env[env].episode = ep; }
+/* explicit reset = a new episode (same convention as mcbs_reset: the episode index feeds the Philox counter) */
+void cbo_reset(void* h, int env) { oracle* o = (oracle*)h; int ep = o->env[env].episode + 1; reset_env(o, &o->env[env]); o->env[env].episode = ep; }
 
 static void obs_slice(const oracle* o, const mcbs_obs_buffers* b, int env, oobs* s) {
     size_t Nm = o->cfg.maximum_node_count, L = o->H->n_local, R = o->H->n_remote, P = o->H->n_ports,

@@ -171,6 +171,7 @@ def run_trace(name, make_env, topo, steps, policy, seed, spec, tape_dps=0, store
     rec["mask_crc"] = []
     reset_obs = flat_obs(obs, topo, info)
     n_disc, n_cache = len(reset_obs["order"]), 0
+    episode = 0
     for t in range(steps):
         if script is not None:
             a = list(script[t]) + [0] * (5 - len(script[t]))
@@ -214,7 +215,8 @@ def run_trace(name, make_env, topo, steps, policy, seed, spec, tape_dps=0, store
             rec[f].append(fo[f])
         rec["mask_crc"].append([zlib.crc32(fo[m].tobytes()) for m in ("mask_local", "mask_remote", "mask_connect")])
         if done:
-            obs, info = env.reset()
+            episode += 1
+            obs, info = env.reset(seed=seed + 1000 * episode)   # reproducible fixtures
             n_disc, n_cache = len(flat_obs(obs, topo, info)["order"]), 0
     out = {k: np.asarray(v) for k, v in rec.items() if len(v)}
     out["actions"] = out["actions"].astype(np.int32)

@@ -1,0 +1,175 @@
+"""GPU parity tests (run on the MI355X box with `pytest -m gpu`): the HIP engine, called through the C ABI,
+against (1) the golden traces captured from the imported reference, (2) the CPU oracle on identical seeded
+action batches, and (3) size-independent properties at BASELINE.json's full batch size."""
+import numpy as np
+import pytest
+
+from tests import parity
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine():
+    from marlon_amd import engine
+    return engine
+
+
+class EngineStepper:
+    """Single-env adapter of BatchEngine for parity.replay (tape-driven defender)."""
+
+    def __init__(self, topo, spec):
+        self.eng = _engine().BatchEngine(topo, spec)
+        self.torch = self.eng.torch
+
+    def reset_observation(self, fields):
+        obs = self.eng.alloc_obs(fields)
+        self.eng.observe(obs)
+        return {k: v.cpu().numpy() for k, v in obs.items()}
+
+    def step(self, actions, tape, want_obs):
+        if tape is not None:
+            self.eng.set_draw_tape(tape)
+        if want_obs:
+            obs = self.eng.alloc_obs(want_obs)
+            r, d = self.eng.step_observe(actions, obs)
+        else:
+            obs = None
+            r, d = self.eng.step(actions)
+        out = dict(reward=r.double().cpu().numpy(), terminated=d.cpu().numpy(),
+                   step_count=self.eng.info["step_count"].cpu().numpy(),
+                   availability=self.eng.info["network_availability"].cpu().numpy(),
+                   raw_reward=self.eng.info["raw_reward"].double().cpu().numpy(),
+                   oob=self.eng.info["out_of_bound"].cpu().numpy())
+        out["obs"] = None if obs is None else {k: v.cpu().numpy() for k, v in obs.items()}
+        _, _, order, cache = self.eng.get_state()
+        out["order"], out["cache"] = order, cache
+        return out
+
+
+@pytest.mark.parametrize("name", parity.trace_names())
+def test_engine_matches_reference_trace_with_observations(name):
+    """mcbs_step_observe == the reference, step by step: rewards, flags, availability bits, all observation fields."""
+    limit = 60 if name.startswith("chain100") else 0      # 8.5 MB connect mask per step
+    assert parity.replay(name, EngineStepper, check_obs=True, limit=limit) > 0
+
+
+@pytest.mark.parametrize("name", parity.trace_names())
+def test_fused_step_matches_reference_trace(name):
+    """mcbs_step (one fused launch, no observation) == the reference on rewards / termination / availability / order."""
+    assert parity.replay(name, EngineStepper, check_obs=False) > 0
+
+
+def _compare_states(a, b, ctx):
+    for x, y, what in zip(a, b, ("header", "nodes", "order", "cache")):
+        if x.dtype.names:
+            for f in x.dtype.names:
+                if f.startswith("pad"):
+                    continue
+                np.testing.assert_array_equal(x[f], y[f], err_msg=f"{ctx}: state {what}.{f}")
+        else:
+            np.testing.assert_array_equal(x, y, err_msg=f"{ctx}: state {what}")
+
+
+CASES = {
+    # name: (topology trace prefix, spec overrides, n_envs, steps)
+    "chain10_attacker": ("chain10_script", dict(), 4096, 200),
+    "toyctf_defender": ("toyctf_defender_s11", dict(), 2048, 200),
+    "chain100_defender": ("chain100_defender_s31", dict(), 512, 120),
+    "sink_defender": ("sink_defender_s43", dict(), 2048, 300),
+    "sink_evict": ("sink_evict_s44", dict(), 1024, 200),
+    "random24_defender": ("random24_defender_s51", dict(), 1024, 200),
+}
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+@pytest.mark.parametrize("policy", ["valid", "uniform"])
+def test_engine_matches_oracle_batched(case, policy):
+    """Thousands of envs, Philox defender draws, device-sampled actions, auto-reset: every output and the full
+    canonical state equal the CPU oracle's."""
+    from marlon_amd._abi import RNG_PHILOX
+    from oracle.oracle import Oracle
+    trace, over, E, steps = CASES[case]
+    _, sj = parity.load_trace(trace)
+    topo = parity.topology_for(trace)
+    spec = parity.spec_from_json(sj, n_envs=E, auto_reset=True, rng_kind=RNG_PHILOX, seed=0xC0FFEE + len(case),
+                                 env_id_base=1000, max_episode_steps=150, **over)
+    eng = _engine().BatchEngine(topo, spec)
+    orc = Oracle(topo, spec)
+    for t in range(steps):
+        a = eng.sample_actions(policy == "valid", seed=77, step=t)
+        r, d = eng.step(a)
+        o = orc.step(a.cpu().numpy())
+        ctx = f"{case}/{policy} step {t}"
+        np.testing.assert_array_equal(r.double().cpu().numpy(), o["reward"], err_msg=ctx + " reward")
+        np.testing.assert_array_equal(eng.info["raw_reward"].double().cpu().numpy(), o["raw_reward"], err_msg=ctx + " raw")
+        np.testing.assert_array_equal(d.cpu().numpy(), o["terminated"], err_msg=ctx + " terminated")
+        np.testing.assert_array_equal(eng.info["truncated"].cpu().numpy(), o["truncated"], err_msg=ctx + " truncated")
+        np.testing.assert_array_equal(eng.info["out_of_bound"].cpu().numpy(), o["oob"], err_msg=ctx + " oob")
+        np.testing.assert_array_equal(eng.info["step_count"].cpu().numpy(), o["step_count"], err_msg=ctx + " step_count")
+        np.testing.assert_array_equal(eng.info["network_availability"].cpu().numpy().view(np.uint64),
+                                      o["availability"].view(np.uint64), err_msg=ctx + " availability bits")
+        if t % 25 == 24 or t == steps - 1:
+            _compare_states(eng.get_state(), orc.get_state(), ctx)
+    eng.close()
+
+
+def test_observations_match_oracle_batched():
+    """Observation kernels vs the oracle's observation for 512 envs in mixed states (ToyCtf + defender)."""
+    from marlon_amd._abi import RNG_PHILOX
+    from oracle.oracle import Oracle
+    _, sj = parity.load_trace("toyctf_defender_s11")
+    topo = parity.topology_for("toyctf")
+    E = 512
+    spec = parity.spec_from_json(sj, n_envs=E, auto_reset=True, rng_kind=RNG_PHILOX, seed=5)
+    eng = _engine().BatchEngine(topo, spec)
+    orc = Oracle(topo, spec)
+    fields = [f for f in parity.OBS_FIELDS]
+    for t in range(60):
+        a = eng.sample_actions(t % 3 != 0, seed=3, step=t)
+        obs = eng.alloc_obs(fields + ["mask_discrete"])
+        eng.step_observe(a, obs)
+        oo = orc.alloc_obs(fields)
+        orc.step(a.cpu().numpy(), obs=oo)
+        for f in fields:
+            np.testing.assert_array_equal(obs[f].cpu().numpy(), oo[f], err_msg=f"step {t} obs {f}")
+        disc = np.concatenate([oo["mask_connect"].reshape(E, -1), oo["mask_local"].reshape(E, -1), oo["mask_remote"].reshape(E, -1)], axis=1)
+        np.testing.assert_array_equal(obs["mask_discrete"].cpu().numpy(), disc, err_msg=f"step {t} mask_discrete")
+    eng.close()
+
+
+def test_full_size_properties_chain10_65536():
+    """BASELINE.json headline size (65 536 envs, Chain-10): determinism, shard invariance (two half batches with
+    env_id_base = the full batch), and state invariants that hold for any action sequence."""
+    from marlon_amd._abi import RNG_PHILOX
+    _, sj = parity.load_trace("chain10_script")
+    topo = parity.topology_for("chain10")
+    E, steps = 65536, 120
+
+    def run(n, base, ids):
+        spec = parity.spec_from_json(sj, n_envs=n, auto_reset=True, rng_kind=RNG_PHILOX, seed=9, env_id_base=base, max_episode_steps=100)
+        eng = _engine().BatchEngine(topo, spec)
+        tot = eng.torch.zeros(n, dtype=eng.torch.float64, device=eng.device)
+        dones = eng.torch.zeros(n, dtype=eng.torch.int64, device=eng.device)
+        for t in range(steps):
+            r, d = eng.step(eng.sample_actions(True, seed=1, step=t))
+            tot += r.double()
+            dones += d.long() + eng.info["truncated"].long()
+        st = eng.get_state()
+        eng.close()
+        return tot.cpu().numpy(), dones.cpu().numpy(), st
+
+    tot, dones, st = run(E, 0, None)
+    tot2, dones2, st2 = run(E, 0, None)
+    np.testing.assert_array_equal(tot, tot2)
+    _compare_states(st, st2, "determinism")
+    h0, d0, s0 = run(E // 2, 0, None)
+    h1, d1, s1 = run(E // 2, E // 2, None)
+    np.testing.assert_array_equal(np.concatenate([h0, h1]), tot)
+    np.testing.assert_array_equal(np.concatenate([d0, d1]), dones)
+    hdr, nodes, order, cache = st
+    assert (dones > 0).all()                                         # every env was truncated at 100 steps at least once
+    assert (hdr["n_discovered"] == nodes["discovered"].sum(axis=1)).all()
+    assert (nodes["installed"] <= nodes["discovered"]).all()
+    assert (nodes["privilege"][nodes["installed"] == 1] >= 1).all()
+    assert (hdr["n_creds"] <= 11).all() and (hdr["step_count"] <= 100).all()
+    assert tot.sum() > 0
