@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X step engine.
+
+Metric (BASELINE.json): env-steps/sec at 65536 envs, CyberBattleChain-10; bit-exact vs CPU ref.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path (`mcbs_step`, one fused kernel launch = CyberBattleEnv.step for every
+env of the rank's shard) over one batch of actions that is already resident in HBM.  Workload per GPU:
+CyberBattleChain size=10, 65 536 envs, attacker only, goal own 100 %, auto-reset, episodes truncated at 2 000
+steps (marlon's max_timesteps, attack_wrapper.py:38); actions are valid random actions in the style of
+CyberBattleEnv.sample_valid_action, recorded by an untimed rollout of the same engine and replayed from an
+HBM ring (the replay is exact: attacker-only Chain has no randomness).  Weak scaling: every rank owns its own
+65 536 envs (global env ids rank*E ..), no collective on the data path; the only collectives are the timing
+barrier / MAX and an optional all_gather of episode returns after the timed region.
+
+The timed region replays the K steps from a hipGraph (launch-bound inner loop captured once), bracketed by
+barrier + synchronize on both sides.  The dominant kernel's duration is measured in the same process with HIP
+events on the launch stream (eager replay of the same K steps) and reported as a fraction of the HBM roofline;
+the CPU oracle (oracle/, a port of the reference's algorithm, NOT the product) is timed on one host core on a
+bounded sample of the same action ring, and its rewards are compared with the GPU's while at it.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+ENVS_PER_GPU = 65536
+B_STEP = 348            # algorithmic bytes per env-step, SURVEY.md section 8(d) (attacker-only tier)
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def build_engine(rank: int, n_envs: int, max_episode_steps: int):
+    from marlon_amd import engine, flatten
+    from marlon_amd._abi import EnvSpec
+    from marlon_amd.samples import chainpattern
+
+    topo = flatten.flatten(chainpattern.new_environment(10))
+    spec = EnvSpec(n_envs=n_envs, maximum_node_count=12, maximum_total_credentials=12,
+                   attacker_goal=dict(own_atleast_percent=1.0), auto_reset=True,
+                   max_episode_steps=max_episode_steps, seed=12345, env_id_base=rank * n_envs)
+    return engine.BatchEngine(topo, spec), topo, spec
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--max-episode-steps", type=int, default=2000)
+    ap.add_argument("--cpu-envs", type=int, default=8192)
+    ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of a hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
+            return 2
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    E, K, W = args.envs_per_gpu, args.steps, args.warmup
+    from marlon_amd._abi import EnvSpec  # noqa: F401
+    eng, topo, spec = build_engine(rank, E, args.max_episode_steps)
+    spec.device = local_rank
+    dev = eng.device
+
+    # ---- untimed: record W+K batches of valid random actions into an HBM ring, then rewind ----
+    ring = torch.empty((W + K, E, 5), dtype=torch.int32, device=dev)
+    for t in range(W + K):
+        eng.sample_actions(True, seed=12345, step=t, out=ring[t])
+        eng.step(ring[t], with_info=False)
+    torch.cuda.synchronize()
+    eng.reset()          # back to the initial state: the replay below repeats the recorded trajectory exactly
+    rewards = torch.empty((K, E), dtype=torch.float32, device=dev)
+    dones = torch.empty((K, E), dtype=torch.uint8, device=dev)
+    lib, h = eng.lib, eng._h
+
+    def launch(t_ring: int, t_out: int, stream: int) -> None:
+        rc = lib.mcbs_step(h, ring[t_ring].data_ptr(), rewards[t_out].data_ptr(), dones[t_out].data_ptr(), None, stream)
+        if rc != 0:
+            raise RuntimeError(lib.mcbs_last_error().decode())
+
+    # ---- warm-up (untimed) ----
+    st = torch.cuda.current_stream().cuda_stream
+    for t in range(W):
+        launch(t, t % K, st)
+    torch.cuda.synchronize()
+
+    graph = None
+    if not args.no_graph:
+        # the K timed steps captured once into a hipGraph (ring / output addresses are fixed per step)
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                s = torch.cuda.current_stream().cuda_stream
+                for t in range(K):
+                    launch(W + t, t, s)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        # graph capture does not execute: state is still "after warm-up"
+
+    # ---- timed region: exactly K steps ----
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    if graph is not None:
+        graph.replay()
+    else:
+        for t in range(K):
+            launch(W + t, t, st)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    reward_sum_timed = rewards.double().sum(dim=0)          # per-env return over the K timed steps
+    n_done = int(dones.sum().item())
+
+    # ---- kernel duration with HIP events on the launch stream: same K steps, eager, from the same start state ----
+    eng.reset()
+    for t in range(W):
+        launch(t, t % K, st)
+    torch.cuda.synchronize()
+    eng.timing_enable(True)
+    for t in range(K):
+        launch(W + t, t, st)
+    kernel_ms, launches = eng.timing_read()
+    eng.timing_enable(False)
+    kernel_us = kernel_ms * 1e3 / max(1, launches)
+    same = bool(torch.equal(rewards.double().sum(dim=0), reward_sum_timed))
+
+    # ---- optional logging collective (not on the data path): episode returns of every rank ----
+    if world > 1:
+        gathered = [torch.empty_like(reward_sum_timed) for _ in range(world)]
+        dist.all_gather(gathered, reward_sum_timed)
+
+    result = None
+    if rank == 0:
+        bytes_per_launch = float(B_STEP) * E
+        achieved = bytes_per_launch / (kernel_us * 1e-6) / 1e9
+        traffic = None
+        tf = os.path.join(REPO, "profiles", "traffic_step_kernel.json")
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get("bytes_per_launch")
+            except Exception:
+                traffic = None
+        result = {
+            "metric": "env-steps/sec at 65536 envs, CyberBattleChain-10; bit-exact vs CPU ref",
+            "value": world * E * K / elapsed,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": elapsed * 1e3 / K,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int32",
+            "data": "synthetic",
+            "config": {"workload": f"CyberBattleChain size=10, {E} envs per GPU, attacker-only, recorded valid random actions, "
+                                   f"auto-reset, truncation at {args.max_episode_steps} steps",
+                       "envs_per_gpu": E, "launch": "hipGraph replay" if graph is not None else "eager",
+                       "episodes_ended_in_timed_region_rank0": n_done},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "mcbs::step_kernel<0>", "kernel_us": kernel_us, "launches_timed": int(launches),
+                         "algorithmic_bytes_per_launch": bytes_per_launch, "bytes_per_env_step": B_STEP,
+                         "replay_rewards_equal_timed_region": same},
+        }
+        if not args.no_cpu_baseline:
+            n = min(args.cpu_envs, E)
+            acts = ring[W:W + K, :n].cpu().numpy()
+            # the oracle starts from reset; the GPU's timed region started after W warm-up steps: feed it those too
+            warm = ring[:W, :n].cpu().numpy()
+            import numpy as _np
+            full = _np.concatenate([warm, acts], axis=0)
+            from oracle.oracle import Oracle
+            import copy
+            s2 = copy.copy(spec)
+            s2.n_envs = n
+            orc = Oracle(topo, s2)
+            for t in range(W):
+                orc.step(full[t])
+            tot = _np.zeros(n)
+            t0 = time.perf_counter()
+            for t in range(W, W + K):
+                tot += orc.step(full[t])["reward"]
+            dt = time.perf_counter() - t0
+            result["cpu_baseline"] = {
+                "value": n * K / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+                "sample": f"first {n} envs x {K} steps of the same action ring ({dt:.1f} s), scalar C oracle oracle/cbs_oracle.c",
+                "rewards_equal_gpu": bool(_np.array_equal(tot, reward_sum_timed[:n].cpu().numpy())),
+            }
+        print(json.dumps(result))
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
