@@ -182,9 +182,10 @@ extern "C" int mcbs_batch_create(const mcbs_topology* topo, const mcbs_batch_cfg
     S.SW = (h->n_cred_strings + 63) / 64; if (!S.SW) S.SW = 1;
     S.TW = (h->n_triples + 63) / 64; if (!S.TW) S.TW = 1;
     S.Cmax = cfg->maximum_total_credentials;
-    S.off_disc = 32u * N;
-    S.off_cred = (uint32_t)align_up(S.off_disc + N, 2);
-    S.body_stride = (uint32_t)align_up((size_t)S.off_cred + 2u * h->n_triples + 2u, 16);
+    S.off_disc = 0;                                                             // u8 discovery order, >= 16 bytes
+    S.off_cred = (uint32_t)align_up((size_t)N, 16);                             // u16 credential cache, >= 32 bytes
+    S.off_rows = (uint32_t)align_up((size_t)S.off_cred + (2u * h->n_triples > 32u ? 2u * h->n_triples : 32u), 32);
+    S.body_stride = (uint32_t)align_up((size_t)S.off_rows + 32u * N, 64);
 
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
@@ -220,7 +221,7 @@ extern "C" int mcbs_batch_create(const mcbs_topology* topo, const mcbs_batch_cfg
         const bool owned0 = (ns[n].flags & MCBS_NODE_INSTALLED0) != 0;
         r.props = owned0 ? ns[n].props : 0;
         r.misc = (owned0 ? ns[n].priv0 : 0u) | ((uint32_t)ns[n].tags0 << 8);
-        memcpy(init.data() + 32u * n, &r, sizeof(r));
+        memcpy(init.data() + S.off_rows + 32u * n, &r, sizeof(r));
     }
     memcpy(init.data() + S.off_disc, topo->host.data() + h->off_init_order, h->n_init_owned);
     e = hipMemcpy(a + o_init, init.data(), init.size(), hipMemcpyHostToDevice);
@@ -241,6 +242,7 @@ extern "C" int mcbs_batch_create(const mcbs_topology* topo, const mcbs_batch_cfg
     C.K = cfg->maximum_discoverable_credentials_per_action;
     C.off_node = h->off_node; C.off_slot_of = h->off_slot_of; C.off_slot = h->off_slot; C.off_payload = h->off_payload;
     C.off_service = h->off_service; C.off_allowed = h->off_allowed; C.off_triple = h->off_triple;
+    C.lds_bytes = h->off_code;
 
     hipLaunchKernelGGL(reset_kernel, dim3((E + 127) / 128), dim3(128), 0, 0, S, b->T, (const uint8_t*)nullptr, 0);
     e = hipDeviceSynchronize();
@@ -305,6 +307,26 @@ static int timing_end(mcbs_batch* b, hipStream_t st, size_t slot) {
     return MCBS_OK;
 }
 
+// Kernel variant: node-mask words kept in registers (1, 2 or 4) and whether the topology tables fit the LDS budget.
+template <int PHASE, int NWT>
+static void launch_step_nw(mcbs_batch* b, const StepIO& io, hipStream_t st) {
+    const uint32_t E = b->S.E, lds = b->C.lds_bytes;
+    if (lds <= 60000u && !getenv("MCBS_NO_LDS_TOPO")) {
+        const uint32_t block = lds <= 8192u ? 64u : 256u;
+        hipLaunchKernelGGL((step_kernel<PHASE, NWT, true>), dim3((E + block - 1) / block), dim3(block), lds, st, b->S, b->T, b->C, io);
+    } else {
+        hipLaunchKernelGGL((step_kernel<PHASE, NWT, false>), dim3((E + 127) / 128), dim3(128), 0, st, b->S, b->T, b->C, io);
+    }
+}
+
+template <int PHASE>
+static int launch_step(mcbs_batch* b, const StepIO& io, hipStream_t st, const char* what) {
+    if (b->S.NW <= 1) launch_step_nw<PHASE, 1>(b, io, st);
+    else if (b->S.NW == 2) launch_step_nw<PHASE, 2>(b, io, st);
+    else launch_step_nw<PHASE, 4>(b, io, st);
+    return launch_ok(what);
+}
+
 extern "C" int mcbs_step(mcbs_batch* b, const int32_t* actions, float* reward, uint8_t* terminated,
                          const mcbs_info_buffers* info, void* stream) {
     if (!b || !actions || !reward || !terminated) return fail(MCBS_EINVAL, "null argument");
@@ -315,8 +337,7 @@ extern "C" int mcbs_step(mcbs_batch* b, const int32_t* actions, float* reward, u
     size_t slot;
     int rc = timing_begin(b, st, &slot);
     if (rc) return rc;
-    hipLaunchKernelGGL(step_kernel<0>, dim3((b->S.E + 127) / 128), dim3(128), 0, st, b->S, b->T, b->C, io);
-    if ((rc = launch_ok("step"))) return rc;
+    if ((rc = launch_step<0>(b, io, st, "step"))) return rc;
     return timing_end(b, st, slot);
 }
 
@@ -377,13 +398,10 @@ extern "C" int mcbs_step_observe(mcbs_batch* b, const int32_t* actions, float* r
         return fail(MCBS_ESTATE, "rng_kind is TAPE but no draw tape was set (mcbs_set_draw_tape)");
     hipStream_t st = (hipStream_t)stream;
     const StepIO io = make_io(b, actions, reward, terminated, info);
-    const dim3 grid((b->S.E + 127) / 128), block(128);
-    hipLaunchKernelGGL(step_kernel<1>, grid, block, 0, st, b->S, b->T, b->C, io);
-    int rc = launch_ok("step (attacker phase)");
+    int rc = launch_step<1>(b, io, st, "step (attacker phase)");
     if (rc) return rc;
     if ((rc = launch_obs(b, obs, st))) return rc;
-    hipLaunchKernelGGL(step_kernel<2>, grid, block, 0, st, b->S, b->T, b->C, io);
-    return launch_ok("step (defender phase)");
+    return launch_step<2>(b, io, st, "step (defender phase)");
 }
 
 extern "C" int mcbs_step_info(mcbs_batch* b, const mcbs_info_buffers* info, void* stream) {
@@ -438,7 +456,7 @@ extern "C" int mcbs_get_state(mcbs_batch* b, void* host_buf, size_t nbytes) {
         const uint8_t* eb = body + (size_t)e * S.body_stride;
         for (uint32_t n = 0; n < S.N; ++n) {
             Row r;
-            memcpy(&r, eb + 32u * n, sizeof(r));
+            memcpy(&r, eb + S.off_rows + 32u * n, sizeof(r));
             const size_t k = (size_t)(n >> 6) * S.E + e;
             const uint64_t bit = 1ull << (n & 63u);
             sn[n].discovered_props = r.props; sn[n].attacked_ever = r.ever; sn[n].attacked_since = r.since;

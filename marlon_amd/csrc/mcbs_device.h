@@ -6,11 +6,12 @@
 //     and one double2 {cum_reward, availability} per env, plus u64 bit-mask columns [word][env] for the
 //     node sets (discovered / agent installed / ever owned / running / privilege>=LocalUser) and for the
 //     gathered-credential and cached-triple sets;
-//   * one "body" record per env (array-of-structures, stride body_stride): 32-byte node rows
-//     (discovered-property mask, attacked-ever / attacked-since-reimage slot masks, privilege, tags,
-//     re-imaging countdown) followed by the discovery order (u8 node ids) and the credential cache
-//     (u16 triple ids).  Rows are gathered by node id, which differs per env, so they sit next to each
-//     other per env rather than along the env axis.
+//   * one "body" record per env (array-of-structures, stride body_stride): the discovery order (u8 node
+//     ids) and the credential cache (u16 triple ids) first — their first 16 entries each are fetched with
+//     the header, before the action is decoded — then 32-byte node rows (discovered-property mask,
+//     attacked-ever / attacked-since-reimage slot masks, privilege, tags, re-imaging countdown).  Rows are
+//     gathered by node id, which differs per env, so they sit next to each other per env rather than
+//     along the env axis.
 //   * the topology blob (include/mcbs.h "MCBT") is shared by every env and read-only.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -50,7 +51,7 @@ struct DevState {
     uint8_t*  body;     // [E][body_stride]
     const uint8_t* init_body; // [body_stride] image of a freshly reset env
     uint32_t E, N, NW, SW, TW;
-    uint32_t body_stride, off_disc, off_cred, Cmax;
+    uint32_t body_stride, off_disc, off_cred, off_rows, Cmax;
 };
 
 struct Topo {           // device view of the MCBT blob
@@ -68,6 +69,7 @@ struct StepCfg {        // the parts of mcbs_batch_cfg the kernels read
     uint32_t L, R, P, V, n_props, K;
     // section offsets into the blob, hoisted so kernels do not chase the header
     uint32_t off_node, off_slot_of, off_slot, off_payload, off_service, off_allowed, off_triple;
+    uint32_t lds_bytes;  // bytes of the blob (header + tables up to the oracle byte code) staged in LDS
 };
 
 struct StepIO {

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void obs_small_kernel(DevState S, Topo T, Step
     const uint32_t kind = (flags >> F_KIND_SHIFT) & 0xFu, level = (flags >> F_LEVEL_SHIFT) & 3u;
     const uint32_t new_nodes = (flags >> F_NEWNODES_SHIFT) & 0x3FFu, new_creds = (flags >> F_NEWCREDS_SHIFT) & 0x3FFu;
     const uint8_t* body = S.body + (size_t)e * S.body_stride;
-    const Row* rows = reinterpret_cast<const Row*>(body);
+    const Row* rows = reinterpret_cast<const Row*>(body + S.off_rows);
     const uint8_t* dl = body + S.off_disc;
     const uint16_t* cl = reinterpret_cast<const uint16_t*>(body + S.off_cred);
     const mcbs_node_static* NS = reinterpret_cast<const mcbs_node_static*>(T.base + C.off_node);
