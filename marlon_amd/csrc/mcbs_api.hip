@@ -51,6 +51,7 @@ struct mcbs_batch {
     ObsDigest* digest = nullptr;
     const double* tape = nullptr;
     uint32_t tape_dps = 0;
+    unsigned long long* stamps = nullptr;   // diagnostic builds: device buffer [waves][8]
     // timing
     bool timing = false;
     std::vector<hipEvent_t> ev;     // pairs (start, stop) per launch
@@ -171,6 +172,9 @@ extern "C" int mcbs_batch_create(const mcbs_topology* topo, const mcbs_batch_cfg
     if (cfg->defender_kind > MCBS_DEFENDER_SCAN_AND_REIMAGE) return fail(MCBS_EINVAL, "unknown defender kind");
     if (cfg->defender_kind == MCBS_DEFENDER_SCAN_AND_REIMAGE && cfg->scan_frequency == 0) return fail(MCBS_EINVAL, "scan_frequency must be positive");
     if (cfg->rng_kind > MCBS_RNG_TAPE) return fail(MCBS_EINVAL, "unknown rng kind");
+    if (h->n_cred_strings > 256u || h->n_triples > 256u)
+        return fail(MCBS_ELIMIT, "this build keeps every set in <= 4 x 64-bit registers per env: at most 256 credential strings / triples "
+                    "(topology has %u / %u)", h->n_cred_strings, h->n_triples);
 
     mcbs_batch* b = new (std::nothrow) mcbs_batch();
     if (!b) return fail(MCBS_ENOMEM, "out of memory");
@@ -190,9 +194,10 @@ extern "C" int mcbs_batch_create(const mcbs_topology* topo, const mcbs_batch_cfg
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     const size_t o_h0 = take(16ull * E), o_h1 = take(16ull * E), o_ep = take(4ull * E), o_pend = take(8ull * E);
-    const size_t o_disc = take(8ull * S.NW * E), o_inst = take(8ull * S.NW * E), o_ever = take(8ull * S.NW * E),
-                 o_run = take(8ull * S.NW * E), o_priv = take(8ull * S.NW * E);
-    const size_t o_gath = take(8ull * S.SW * E), o_cach = take(8ull * S.TW * E);
+    size_t o_mask[M_COUNT];
+    for (int k = 0; k < M_COUNT; ++k) o_mask[k] = take(8ull * (k == M_GATH ? S.SW : (k == M_CACH ? S.TW : S.NW)) * E);
+    const bool has_def = cfg->defender_kind != MCBS_DEFENDER_NONE;
+    const size_t o_ring = has_def ? take(8ull * 16 * S.NW * E) : 0;
     const size_t o_init = take(S.body_stride);
     const size_t o_digest = take(sizeof(ObsDigest) * (size_t)E);
     const size_t o_body = take((size_t)S.body_stride * E);
@@ -204,10 +209,8 @@ extern "C" int mcbs_batch_create(const mcbs_topology* topo, const mcbs_batch_cfg
     uint8_t* a = b->arena;
     S.h0 = reinterpret_cast<uint4*>(a + o_h0); S.h1 = reinterpret_cast<double2*>(a + o_h1);
     S.episode = reinterpret_cast<uint32_t*>(a + o_ep); S.pending = reinterpret_cast<double*>(a + o_pend);
-    S.m_disc = reinterpret_cast<uint64_t*>(a + o_disc); S.m_inst = reinterpret_cast<uint64_t*>(a + o_inst);
-    S.m_ever = reinterpret_cast<uint64_t*>(a + o_ever); S.m_run = reinterpret_cast<uint64_t*>(a + o_run);
-    S.m_priv = reinterpret_cast<uint64_t*>(a + o_priv); S.m_gath = reinterpret_cast<uint64_t*>(a + o_gath);
-    S.m_cach = reinterpret_cast<uint64_t*>(a + o_cach);
+    for (int k = 0; k < M_COUNT; ++k) S.mask[k] = reinterpret_cast<uint64_t*>(a + o_mask[k]);
+    S.ring = has_def ? reinterpret_cast<uint64_t*>(a + o_ring) : nullptr;
     S.body = a + o_body; S.init_body = a + o_init;
     b->digest = reinterpret_cast<ObsDigest*>(a + o_digest);
     b->T.base = topo->dev;
@@ -220,7 +223,7 @@ extern "C" int mcbs_batch_create(const mcbs_topology* topo, const mcbs_batch_cfg
         Row r{};
         const bool owned0 = (ns[n].flags & MCBS_NODE_INSTALLED0) != 0;
         r.props = owned0 ? ns[n].props : 0;
-        r.misc = (owned0 ? ns[n].priv0 : 0u) | ((uint32_t)ns[n].tags0 << 8);
+        r.tags = ns[n].tags0;
         memcpy(init.data() + S.off_rows + 32u * n, &r, sizeof(r));
     }
     memcpy(init.data() + S.off_disc, topo->host.data() + h->off_init_order, h->n_init_owned);
@@ -286,6 +289,7 @@ static StepIO make_io(mcbs_batch* b, const int32_t* actions, float* reward, uint
         io.oob = info->out_of_bound; io.raw_reward = info->raw_reward;
     }
     io.tape = b->tape; io.tape_dps = b->tape_dps;
+    io.stamps = b->stamps;
     return io;
 }
 
@@ -321,8 +325,11 @@ static void launch_step_nw(mcbs_batch* b, const StepIO& io, hipStream_t st) {
 
 template <int PHASE>
 static int launch_step(mcbs_batch* b, const StepIO& io, hipStream_t st, const char* what) {
-    if (b->S.NW <= 1) launch_step_nw<PHASE, 1>(b, io, st);
-    else if (b->S.NW == 2) launch_step_nw<PHASE, 2>(b, io, st);
+    uint32_t wt = b->S.NW;
+    if (b->S.SW > wt) wt = b->S.SW;
+    if (b->S.TW > wt) wt = b->S.TW;
+    if (wt <= 1) launch_step_nw<PHASE, 1>(b, io, st);
+    else if (wt == 2) launch_step_nw<PHASE, 2>(b, io, st);
     else launch_step_nw<PHASE, 4>(b, io, st);
     return launch_ok(what);
 }
@@ -438,8 +445,9 @@ extern "C" int mcbs_get_state(mcbs_batch* b, void* host_buf, size_t nbytes) {
     const uint4* h0 = reinterpret_cast<const uint4*>(at(S.h0));
     const double2* h1 = reinterpret_cast<const double2*>(at(S.h1));
     const uint32_t* ep = reinterpret_cast<const uint32_t*>(at(S.episode));
-    const uint64_t* md = reinterpret_cast<const uint64_t*>(at(S.m_disc)), *mi = reinterpret_cast<const uint64_t*>(at(S.m_inst)),
-                   *me = reinterpret_cast<const uint64_t*>(at(S.m_ever)), *mr = reinterpret_cast<const uint64_t*>(at(S.m_run));
+    const uint64_t* mk[M_COUNT];
+    for (int k = 0; k < M_COUNT; ++k) mk[k] = reinterpret_cast<const uint64_t*>(at(S.mask[k]));
+    const uint64_t* ring = S.ring ? reinterpret_cast<const uint64_t*>(at(S.ring)) : nullptr;
     const uint8_t* body = at(S.body);
     memset(host_buf, 0, rb * S.E);
     for (uint32_t e = 0; e < S.E; ++e) {
@@ -460,10 +468,16 @@ extern "C" int mcbs_get_state(mcbs_batch* b, void* host_buf, size_t nbytes) {
             const size_t k = (size_t)(n >> 6) * S.E + e;
             const uint64_t bit = 1ull << (n & 63u);
             sn[n].discovered_props = r.props; sn[n].attacked_ever = r.ever; sn[n].attacked_since = r.since;
-            sn[n].discovered = (md[k] & bit) != 0; sn[n].installed = (mi[k] & bit) != 0; sn[n].ever_owned = (me[k] & bit) != 0;
-            sn[n].running = (mr[k] & bit) != 0;
-            sn[n].privilege = (uint8_t)(r.misc & 0xFFu); sn[n].tags = (uint8_t)((r.misc >> 8) & 0xFFu);
-            sn[n].countdown = sn[n].running ? 0 : (uint8_t)((r.misc >> 16) & 0xFFu);
+            sn[n].discovered = (mk[M_DISC][k] & bit) != 0; sn[n].installed = (mk[M_INST][k] & bit) != 0;
+            sn[n].ever_owned = (mk[M_EVER][k] & bit) != 0; sn[n].running = (mk[M_RUN][k] & bit) != 0;
+            sn[n].privilege = (uint8_t)(((mk[M_PLO][k] & bit) ? 1 : 0) | ((mk[M_PHI][k] & bit) ? 2 : 0));
+            sn[n].tags = (uint8_t)(r.tags & 0xFFu);
+            sn[n].countdown = 0;
+            if (!sn[n].running && ring) {   // remaining steps = distance from the defender clock to the node's ring slot
+                const uint32_t d = (h0[e].w >> 16) & 15u;
+                for (uint32_t s = 0; s < 16u; ++s)
+                    if (ring[((size_t)s * S.NW + (n >> 6)) * S.E + e] & bit) sn[n].countdown = (uint8_t)((s + 16u - d) & 15u);
+            }
         }
         uint16_t* order = reinterpret_cast<uint16_t*>(p + sizeof(mcbs_state_header) + sizeof(mcbs_state_node) * S.N);
         for (uint32_t k = 0; k < S.N; ++k) order[k] = k < sh->n_discovered ? eb[S.off_disc + k] : 0xFFFF;
@@ -477,6 +491,13 @@ extern "C" int mcbs_get_state(mcbs_batch* b, void* host_buf, size_t nbytes) {
 extern "C" int mcbs_set_state(mcbs_batch* b, const void* host_buf, size_t nbytes) {
     (void)b; (void)host_buf; (void)nbytes;
     return fail(MCBS_ESTATE, "mcbs_set_state is not implemented in this round");
+}
+
+// diagnostic builds (-DMCBS_DIAG): per-wavefront s_memtime stamps of the next step launches; not part of the public ABI
+extern "C" int mcbs_diag_set_stamps(mcbs_batch* b, unsigned long long* dev_buf) {
+    if (!b) return fail(MCBS_EINVAL, "null batch");
+    b->stamps = dev_buf;
+    return MCBS_OK;
 }
 
 // ------------------------------------------------------------------ timing

@@ -31,23 +31,22 @@ struct Row {            // 32 bytes
     uint64_t props;     // discovered properties
     uint32_t ever;      // slot s exploited at least once            (actions.py:396-407)
     uint32_t since;     // ... and not re-imaged since
-    uint32_t misc;      // privilege | tags << 8 | countdown << 16
+    uint32_t tags;      // privilege_k tags appended to node.properties (actions.py:378), 4 bits
     uint32_t spare[3];
 };
 static_assert(sizeof(Row) == 32, "row");
 
+// node-set and credential-set columns, [word][env] u64 each
+enum { M_DISC = 0, M_INST, M_EVER, M_RUN, M_PLO, M_PHI, M_GATH, M_CACH, M_COUNT };
+
 struct DevState {
-    uint4*    h0;       // [E] {step_count, flags, n_discovered | n_creds << 16, owned_count | imaging_count << 16}
+    uint4*    h0;       // [E] {step_count, flags, n_discovered | n_creds << 16, owned_count | defender_clock << 16}
     double2*  h1;       // [E] {cum_reward, availability}
     uint32_t* episode;  // [E]
     double*   pending;  // [E] raw reward carried between the split phases of mcbs_step_observe
-    uint64_t* m_disc;   // [NW][E]
-    uint64_t* m_inst;
-    uint64_t* m_ever;
-    uint64_t* m_run;
-    uint64_t* m_priv;
-    uint64_t* m_gath;   // [SW][E]
-    uint64_t* m_cach;   // [TW][E]
+    uint64_t* mask[M_COUNT]; // discovered / agent installed / ever owned / running / privilege bit 0 / bit 1 : [NW][E]
+                             // gathered credential strings [SW][E], cached credential triples [TW][E]
+    uint64_t* ring;     // [16][NW][E] nodes being re-imaged, by the defender tick (mod 16) that releases them; null without defender
     uint8_t*  body;     // [E][body_stride]
     const uint8_t* init_body; // [body_stride] image of a freshly reset env
     uint32_t E, N, NW, SW, TW;
@@ -83,6 +82,7 @@ struct StepIO {
     float* raw_reward;
     const double* tape;
     uint32_t tape_dps;
+    unsigned long long* stamps;  // diagnostic builds only (-DMCBS_DIAG): [waves][8] s_memtime stamps
 };
 
 struct ObsIO {
@@ -115,17 +115,26 @@ __device__ __forceinline__ double to_double53(uint32_t a, uint32_t b) {
 __device__ __forceinline__ void reset_header(const DevState& S, const Topo& T, uint32_t e, uint32_t episode) {
     const mcbs_topo_header& H = T.H();
     const uint8_t* order = T.base + H.off_init_order;
+    const mcbs_node_static* ns = reinterpret_cast<const mcbs_node_static*>(T.base + H.off_node);
     const uint32_t n_init = H.n_init_owned;
     for (uint32_t w = 0; w < S.NW; ++w) {
-        uint64_t m = 0;
-        for (uint32_t i = 0; i < n_init; ++i) { const uint32_t n = order[i]; if ((n >> 6) == w) m |= 1ull << (n & 63u); }
+        uint64_t m = 0, lo = 0, hi = 0;
+        for (uint32_t i = 0; i < n_init; ++i) {
+            const uint32_t n = order[i];
+            if ((n >> 6) != w) continue;
+            const uint64_t bit = 1ull << (n & 63u);
+            m |= bit;
+            if (ns[n].priv0 & 1u) lo |= bit;
+            if (ns[n].priv0 & 2u) hi |= bit;
+        }
         const uint32_t rem = S.N - w * 64u;
         const size_t k = (size_t)w * S.E + e;
-        S.m_disc[k] = m; S.m_inst[k] = m; S.m_ever[k] = m; S.m_priv[k] = m;
-        S.m_run[k] = rem >= 64u ? ~0ull : ((1ull << rem) - 1ull);
+        S.mask[M_DISC][k] = m; S.mask[M_INST][k] = m; S.mask[M_EVER][k] = m; S.mask[M_PLO][k] = lo; S.mask[M_PHI][k] = hi;
+        S.mask[M_RUN][k] = rem >= 64u ? ~0ull : ((1ull << rem) - 1ull);
+        if (S.ring) for (uint32_t s = 0; s < 16u; ++s) S.ring[((size_t)s * S.NW + w) * S.E + e] = 0;
     }
-    for (uint32_t w = 0; w < S.SW; ++w) S.m_gath[(size_t)w * S.E + e] = 0;
-    for (uint32_t w = 0; w < S.TW; ++w) S.m_cach[(size_t)w * S.E + e] = 0;
+    for (uint32_t w = 0; w < S.SW; ++w) S.mask[M_GATH][(size_t)w * S.E + e] = 0;
+    for (uint32_t w = 0; w < S.TW; ++w) S.mask[M_CACH][(size_t)w * S.E + e] = 0;
     S.h0[e] = make_uint4(0u, 0u, n_init, n_init);
     S.h1[e] = make_double2(0.0, 1.0);
     S.episode[e] = episode;

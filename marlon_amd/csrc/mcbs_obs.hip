@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void obs_small_kernel(DevState S, Topo T, Step
             if (i < n_disc) {
                 const uint32_t n = dl[i];
                 ext_of[n] = (uint8_t)i;
-                own = (S.m_inst[(size_t)(n >> 6) * S.E + e] >> (n & 63u)) & 1ull;
+                own = (S.mask[M_INST][(size_t)(n >> 6) * S.E + e] >> (n & 63u)) & 1ull;
             }
             own_ext[c] = __ballot(own);
         }
@@ -118,7 +118,15 @@ __global__ __launch_bounds__(256) void obs_small_kernel(DevState S, Topo T, Step
     }
     if (O.priv) {
         int32_t* out = O.priv + (size_t)e * Nm;
-        for (uint32_t i = lane; i < Nm; i += 64u) out[i] = (!blank && i < n_disc) ? (int32_t)(rows[dl[i]].misc & 0xFFu) : 0;
+        for (uint32_t i = lane; i < Nm; i += 64u) {
+            int32_t v = 0;
+            if (!blank && i < n_disc) {
+                const uint32_t n = dl[i];
+                const size_t k = (size_t)(n >> 6) * S.E + e;
+                v = (int32_t)(((S.mask[M_PLO][k] >> (n & 63u)) & 1ull) | (((S.mask[M_PHI][k] >> (n & 63u)) & 1ull) << 1));
+            }
+            out[i] = v;
+        }
     }
     if (O.mask_local) {
         int8_t* out = O.mask_local + (size_t)e * Nm * L;

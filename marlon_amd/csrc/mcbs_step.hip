@@ -13,13 +13,16 @@
 // therefore organised by dependency level, not by reference function:
 //   level 1 (addresses depend on the env index only, issued back to back, all coalesced along the env axis):
 //           header uint4, action row, first 16 discovery-order entries, first 16 credential-cache entries,
-//           the agent-installed and running node masks, {cum_reward, availability};
+//           EVERY set of the env as u64 bit-mask words (discovered, agent installed, ever owned, running,
+//           privilege bit-planes, gathered credentials, cached credential triples), {cum_reward, availability};
 //           meanwhile the workgroup copies the topology tables into LDS;
-//   level 2 (address depends on the action): the target node's 32-byte row (and list entries beyond the
-//           first 16 for large topologies);
-//   then pure ALU + LDS look-ups (vulnerability slot, payload, firewall / service tables), and one round
-//   of stores (row, masks, header, outputs).  Rare events (discoveries, ownership changes, re-imaging)
-//   touch further mask columns / rows lazily.
+//   level 2 (address depends on the action / header): the target node's 32-byte row, the re-imaging ring slot
+//           of this defender tick (and list entries beyond the first 16 for large topologies);
+//   then pure register + LDS work (vulnerability slot, payload, firewall / service tables, Philox), and one
+//   round of stores (row, changed masks, list appends, header, outputs).  "Rare" events are not rare per
+//   wavefront (64 envs), so nothing on those paths may cost another trip to memory: a first version that
+//   tested the ever-owned / discovered / credential sets lazily in memory spent 9 of its 10 dependency levels
+//   there (profiles/round1_notes.md).
 //
 // Rules restated from the reference (citations = /root/reference/src/CyberBattleSim/cyberbattle/...):
 //   _env/cyberbattle_env.py : step 1145-1185, __execute_action 707-751, index translation 584-601,
@@ -38,41 +41,29 @@
 
 namespace mcbs {
 
-// ------------------------------ bit-mask columns [word][env] in memory ------------------------------
-__device__ __forceinline__ bool mtest(const uint64_t* col, uint32_t E, uint32_t e, uint32_t bit) {
-    return (col[(size_t)(bit >> 6) * E + e] >> (bit & 63u)) & 1ull;
-}
-__device__ __forceinline__ bool mtestset(uint64_t* col, uint32_t E, uint32_t e, uint32_t bit) {
-    uint64_t* p = &col[(size_t)(bit >> 6) * E + e];
-    const uint64_t w = *p, m = 1ull << (bit & 63u);
-    if (w & m) return true;
-    *p = w | m;
-    return false;
-}
-__device__ __forceinline__ void mset(uint64_t* col, uint32_t E, uint32_t e, uint32_t bit) {
-    col[(size_t)(bit >> 6) * E + e] |= 1ull << (bit & 63u);
-}
-__device__ __forceinline__ void mclear(uint64_t* col, uint32_t E, uint32_t e, uint32_t bit) {
-    col[(size_t)(bit >> 6) * E + e] &= ~(1ull << (bit & 63u));
-}
-
-// ------------------------------ node masks held in registers (NWT words) ------------------------------
-template <int NWT>
-__device__ __forceinline__ bool rget(const uint64_t (&m)[NWT], uint32_t n) {
+// ------------------------------ sets held in registers (WT words each) ------------------------------
+template <int WT>
+__device__ __forceinline__ bool rget(const uint64_t (&m)[WT], uint32_t n) {
     uint64_t w = m[0];
 #pragma unroll
-    for (int i = 1; i < NWT; ++i) if ((n >> 6) == (uint32_t)i) w = m[i];
+    for (int i = 1; i < WT; ++i) if ((n >> 6) == (uint32_t)i) w = m[i];
     return (w >> (n & 63u)) & 1ull;
 }
-template <int NWT>
-__device__ __forceinline__ void rset(uint64_t (&m)[NWT], uint32_t n) {
+template <int WT>
+__device__ __forceinline__ void rset(uint64_t (&m)[WT], uint32_t n) {
 #pragma unroll
-    for (int i = 0; i < NWT; ++i) if ((n >> 6) == (uint32_t)i) m[i] |= 1ull << (n & 63u);
+    for (int i = 0; i < WT; ++i) if ((n >> 6) == (uint32_t)i) m[i] |= 1ull << (n & 63u);
 }
-template <int NWT>
-__device__ __forceinline__ void rclear(uint64_t (&m)[NWT], uint32_t n) {
+template <int WT>
+__device__ __forceinline__ void rclear(uint64_t (&m)[WT], uint32_t n) {
 #pragma unroll
-    for (int i = 0; i < NWT; ++i) if ((n >> 6) == (uint32_t)i) m[i] &= ~(1ull << (n & 63u));
+    for (int i = 0; i < WT; ++i) if ((n >> 6) == (uint32_t)i) m[i] &= ~(1ull << (n & 63u));
+}
+template <int WT>   // returns the previous value of the bit
+__device__ __forceinline__ bool rtestset(uint64_t (&m)[WT], uint32_t n) {
+    const bool was = rget<WT>(m, n);
+    rset<WT>(m, n);
+    return was;
 }
 
 __device__ __forceinline__ uint32_t pick4(const uint4& v, uint32_t i) {
@@ -80,18 +71,19 @@ __device__ __forceinline__ uint32_t pick4(const uint4& v, uint32_t i) {
 }
 
 // ------------------------------ per-lane working set ------------------------------
-template <int NWT>
+template <int WT>
 struct Lane {
     const DevState& S;
     const StepCfg& C;
     const uint8_t* tb;   // topology tables (LDS copy or the blob in global memory)
     uint32_t e;
     uint8_t* body;
-    uint32_t n_disc, n_creds, owned, imaging;
-    uint64_t inst[NWT], run[NWT];
+    uint32_t n_disc, n_creds, owned, dclk;
+    uint64_t m[M_COUNT][WT];
+    uint32_t dirty;      // bit k: set k changed and must be written back
     // the target node's row, in registers
     uint64_t props;
-    uint32_t ever, since, misc;
+    uint32_t ever, since, tags;
     bool row_dirty;
     // result of the attacker's action
     double raw;
@@ -105,17 +97,29 @@ struct Lane {
     __device__ __forceinline__ uint16_t* cred_list() const { return reinterpret_cast<uint16_t*>(body + S.off_cred); }
     __device__ __forceinline__ void done_with(double r, int kind) { raw = r; okind = kind; }
 
-    // __mark_node_as_owned (actions.py:251-275) on the row held in registers.
-    // Returns "was owned at some point before" (last_owned_at is not None); `already` = currently owned.
+    __device__ __forceinline__ uint32_t privilege(uint32_t n) const {
+        return (uint32_t)rget<WT>(m[M_PLO], n) | ((uint32_t)rget<WT>(m[M_PHI], n) << 1);
+    }
+    __device__ __forceinline__ void set_privilege(uint32_t n, uint32_t p) {
+        if (p & 1u) rset<WT>(m[M_PLO], n); else rclear<WT>(m[M_PLO], n);
+        if (p & 2u) rset<WT>(m[M_PHI], n); else rclear<WT>(m[M_PHI], n);
+        dirty |= (1u << M_PLO) | (1u << M_PHI);
+    }
+
+    // __mark_node_as_owned (actions.py:251-275).  Returns "was owned at some point before" (last_owned_at is not
+    // None); `already` = currently owned (agent_installed, see the header comment on logical time).
     __device__ __forceinline__ bool mark_owned(uint32_t n, uint32_t level, bool& already) {
-        already = rget<NWT>(inst, n);
+        already = rget<WT>(m[M_INST], n);
         if (already) return true;                                   // currently owned implies owned before
-        const bool ever_owned = mtestset(S.m_ever, S.E, e, n);
-        rset<NWT>(inst, n);
-        const uint32_t priv = misc & 0xFFu;
+        const bool ever_owned = rtestset<WT>(m[M_EVER], n);
+        rset<WT>(m[M_INST], n);
+        dirty |= (1u << M_EVER) | (1u << M_INST);
+        const uint32_t priv = privilege(n);
         const uint32_t np = priv > level ? priv : level;           // model.escalate
-        if (np >= 1u && priv == 0u) { mset(S.m_priv, S.E, e, n); owned += 1; }
-        misc = (misc & ~0xFFu) | np;
+        if (np != priv) {
+            set_privilege(n, np);
+            if (priv == 0u) owned += 1;
+        }
         props |= NS(n)->props;                                      // all (non-tag) properties become known
         row_dirty = true;
         return ever_owned;
@@ -124,12 +128,11 @@ struct Lane {
     // __process_outcome (actions.py:325-423) with __mark_discovered_entities (277-310) and the env-side
     // appends of cyberbattle_env.py:863-907 fused (both sides keep the same sets, in the same order).
     __device__ __forceinline__ void process_outcome(uint32_t tgt, uint32_t col, double failed_penalty) {
-        if (!rget<NWT>(run, tgt)) return done_with(0.0, MCBS_OUT_NONE);                       // MACHINE_NOT_RUNNING
-        const uint32_t s = (tb + C.off_slot_of)[(size_t)tgt * (C.L + C.R) + col];
+        if (!rget<WT>(m[M_RUN], tgt)) return done_with(0.0, MCBS_OUT_NONE);                   // MACHINE_NOT_RUNNING
+        const uint32_t s = (tb + C.off_slot_of)[tgt * (C.L + C.R) + col];
         if (s == 0xFFu) return done_with(-5.0, MCBS_OUT_NONE);                               // SUPSPICIOUSNESS
-        const uint4* vp = reinterpret_cast<const uint4*>(tb + C.off_slot + ((size_t)tgt * C.V + s) * sizeof(mcbs_vuln_slot));
+        const uint4* vp = reinterpret_cast<const uint4*>(tb + C.off_slot + (tgt * C.V + s) * (uint32_t)sizeof(mcbs_vuln_slot));
         const uint4 v0 = vp[0], v1 = vp[1];   // {cost lo,hi, probe lo,hi} {payload_off, cnt | tt << 16, code_off, code_len | kind << 16 | level << 24}
-        const uint32_t tags = (misc >> 8) & 0xFu;
         const uint32_t kind = (v1.w >> 16) & 0xFFu, level = v1.w >> 24;
         if (!(((v1.y >> 16) >> tags) & 1u)) return done_with(failed_penalty, MCBS_OUT_EXPLOIT_FAILED);
 
@@ -139,7 +142,7 @@ struct Lane {
             if ((tags >> level) & 1u) return done_with(-1.0, MCBS_OUT_PRIVILEGE_ESCALATION);  // REPEAT, nothing recorded
             bool already;
             if (!mark_owned(tgt, level, already)) r += NS(tgt)->value;
-            misc |= (1u << level) << 8;
+            tags |= 1u << level;
         } else if (kind == MCBS_OUT_LATERAL_MOVE) {
             bool already;
             if (!mark_owned(tgt, 1u, already)) r += NS(tgt)->value;
@@ -155,15 +158,17 @@ struct Lane {
 
         int nn = 0, nc = 0;
         if (kind == MCBS_OUT_LEAKED_CREDENTIALS || kind == MCBS_OUT_LEAKED_NODES) {
-            const uint32_t off = v1.x, cnt = v1.y & 0xFFFFu;
-            const uint2* pl = reinterpret_cast<const uint2*>(tb + C.off_payload) + off;
+            const uint32_t cnt = v1.y & 0xFFFFu;
+            const uint2* pl = reinterpret_cast<const uint2*>(tb + C.off_payload) + v1.x;
             for (uint32_t i = 0; i < cnt; ++i) {
                 const uint2 p = pl[i];                   // {node | cred << 16, triple | port << 16}
                 const uint32_t pn = p.x & 0xFFFFu;
-                if (!mtestset(S.m_disc, S.E, e, pn)) { disc_list()[n_disc++] = (uint8_t)pn; nn++; }
+                if (!rtestset<WT>(m[M_DISC], pn)) { disc_list()[n_disc++] = (uint8_t)pn; nn++; dirty |= 1u << M_DISC; }
                 if (kind == MCBS_OUT_LEAKED_CREDENTIALS) {
-                    if (!mtestset(S.m_gath, S.E, e, p.x >> 16)) nc++;
-                    if (!mtestset(S.m_cach, S.E, e, p.y & 0xFFFFu)) { cred_list()[n_creds++] = (uint16_t)(p.y & 0xFFFFu); new_creds++; }
+                    if (!rtestset<WT>(m[M_GATH], p.x >> 16)) { nc++; dirty |= 1u << M_GATH; }
+                    if (!rtestset<WT>(m[M_CACH], p.y & 0xFFFFu)) {
+                        cred_list()[n_creds++] = (uint16_t)(p.y & 0xFFFFu); new_creds++; dirty |= 1u << M_CACH;
+                    }
                 }
             }
         }
@@ -175,14 +180,14 @@ struct Lane {
 
     // connect_to_remote_machine (actions.py:524-606); the credential index was checked against the cache length
     __device__ __forceinline__ void connect(uint32_t src, uint32_t tgt, uint32_t port, uint32_t triple) {
-        if (!rget<NWT>(inst, src)) return done_with(-1.0, MCBS_OUT_NONE);
+        if (!rget<WT>(m[M_INST], src)) return done_with(-1.0, MCBS_OUT_NONE);
         // target is discovered and the credential gathered by construction (both come from this env's own lists)
         const uint32_t cred = (reinterpret_cast<const mcbs_triple*>(tb + C.off_triple) + triple)->cred;
         const mcbs_node_static* t = NS(tgt);
         if (!((NS(src)->fw_out_allow >> port) & 1u)) return done_with(-10.0, MCBS_OUT_NONE);  // BLOCKED_BY_LOCAL_FIREWALL
         if (!((t->fw_in_allow >> port) & 1u)) return done_with(-10.0, MCBS_OUT_NONE);         // BLOCKED_BY_REMOTE_FIREWALL
         if (!((t->listen >> port) & 1u)) return done_with(-10.0, MCBS_OUT_NONE);              // SCANNING_UNOPEN_PORT
-        if (!rget<NWT>(run, tgt)) return done_with(0.0, MCBS_OUT_NONE);                        // MACHINE_NOT_RUNNING
+        if (!rget<WT>(m[M_RUN], tgt)) return done_with(0.0, MCBS_OUT_NONE);                    // MACHINE_NOT_RUNNING
         bool authorized = false;                                                              // actions.py:608-621
         const mcbs_service* sv = reinterpret_cast<const mcbs_service*>(tb + C.off_service) + t->svc_off;
         const uint16_t* allowed = reinterpret_cast<const uint16_t*>(tb + C.off_allowed);
@@ -200,12 +205,11 @@ struct Lane {
     }
 
     // ---- defender ----
-    __device__ __forceinline__ double draw(uint32_t i, uint32_t step, const StepIO& io) const {
+    __device__ __forceinline__ double draw(uint32_t i, uint32_t step, uint32_t episode, const StepIO& io) const {
         if (C.rng_kind == MCBS_RNG_TAPE) return (io.tape && i < io.tape_dps) ? io.tape[(size_t)e * io.tape_dps + i] : 0.0;
         const uint64_t gid = C.env_id_base + e;
         uint32_t r[4];
-        philox4x32_10((uint32_t)gid, S.episode[e], step, i >> 1, (uint32_t)C.seed,
-                      (uint32_t)(C.seed >> 32) ^ (uint32_t)(gid >> 32), r);
+        philox4x32_10((uint32_t)gid, episode, step, i >> 1, (uint32_t)C.seed, (uint32_t)(C.seed >> 32) ^ (uint32_t)(gid >> 32), r);
         return (i & 1u) ? to_double53(r[2], r[3]) : to_double53(r[0], r[1]);
     }
 
@@ -214,72 +218,73 @@ struct Lane {
         return rem >= 64u ? ~0ull : ((1ull << rem) - 1ull);
     }
 
-    // on_attacker_step_taken (actions.py:714-746) -> availability
-    __device__ __forceinline__ double defender_tick() {
-        if (imaging) {
+    // on_attacker_step_taken (actions.py:714-746): nodes whose re-imaging started 16 defender ticks ago are back
+    // (REIMAGING_DURATION 15 -> 0, then Running); `back` = this tick's ring slot.  Returns the availability.
+    __device__ __forceinline__ double defender_tick(const uint64_t (&back)[WT]) {
+        uint32_t imaging = 0;
 #pragma unroll
-            for (int w = 0; w < NWT; ++w) {
-                if ((uint32_t)w >= S.NW) break;
-                uint64_t im = ~run[w] & valid_bits(w);
-                while (im) {
-                    const uint32_t b = (uint32_t)__builtin_ctzll(im);
-                    im &= im - 1;
-                    uint32_t* pm = &row(w * 64u + b)->misc;
-                    const uint32_t m = *pm;
-                    if ((m >> 16) & 0xFFu) *pm = m - (1u << 16);
-                    else { run[w] |= 1ull << b; imaging -= 1; }
-                }
-            }
+        for (int w = 0; w < WT; ++w) {
+            if (back[w]) { m[M_RUN][w] |= back[w]; dirty |= 1u << M_RUN; }
+            if ((uint32_t)w < S.NW) imaging += __popcll(~m[M_RUN][w] & valid_bits(w));
         }
         if (!imaging) return C.full_availability;
         double s;
         if (C.avail_any_order) {          // exact in any order: subtract the terms of the nodes being re-imaged
             s = C.full_sum;
 #pragma unroll
-            for (int w = 0; w < NWT; ++w) {
+            for (int w = 0; w < WT; ++w) {
                 if ((uint32_t)w >= S.NW) break;
-                uint64_t im = ~run[w] & valid_bits(w);
+                uint64_t im = ~m[M_RUN][w] & valid_bits(w);
                 while (im) { const uint32_t b = (uint32_t)__builtin_ctzll(im); im &= im - 1; s -= NS(w * 64u + b)->avail_term; }
             }
         } else {                          // the reference's node-order sum
             s = 0.0;
-            for (uint32_t n = 0; n < S.N; ++n) if (rget<NWT>(run, n)) s += NS(n)->avail_term;
+            for (uint32_t n = 0; n < S.N; ++n) if (rget<WT>(m[M_RUN], n)) s += NS(n)->avail_term;
         }
         return s / C.total_sla_weight;
     }
 
-    // ScanAndReimageCompromisedMachines.step (defender.py:42-55) + reimage_node (actions.py:700-712)
-    __device__ __forceinline__ void defender_scan(uint32_t step, const StepIO& io) {
+    // ScanAndReimageCompromisedMachines.step (defender.py:42-55) + reimage_node (actions.py:700-712).
+    // Nodes re-imaged now are collected in `fresh`: they come back 16 ticks from now (same ring slot).
+    __device__ __forceinline__ void defender_scan(uint32_t step, uint32_t episode, const StepIO& io, uint64_t (&fresh)[WT]) {
         if (step % C.scan_frequency) return;
         uint32_t det = 0;
         for (uint32_t i = 0; i < C.scan_capacity; ++i) {
-            int n = (int)floor(draw(i, step, io) * (double)S.N);
+            int n = (int)floor(draw(i, step, episode, io) * (double)S.N);
             if (n >= (int)S.N) n = (int)S.N - 1;
-            if (!rget<NWT>(run, (uint32_t)n) || !rget<NWT>(inst, (uint32_t)n)) continue;
-            const double d = draw(C.scan_capacity + det, step, io);
+            if (!rget<WT>(m[M_RUN], (uint32_t)n) || !rget<WT>(m[M_INST], (uint32_t)n)) continue;
+            const double d = draw(C.scan_capacity + det, step, episode, io);
             det += 1;
             if (!(d <= C.scan_probability) || !(NS((uint32_t)n)->flags & MCBS_NODE_REIMAGABLE)) continue;
-            Row* rp = row((uint32_t)n);
-            const uint32_t m = rp->misc;
-            rp->misc = (m & 0x0000FF00u) | (15u << 16);          // privilege NoAccess, tags kept, REIMAGING_DURATION
-            rp->since = 0;                                       // every earlier attack now predates last_reimaging
-            rclear<NWT>(inst, (uint32_t)n);
-            if (m & 0xFFu) { mclear(S.m_priv, S.E, e, (uint32_t)n); owned -= 1; }
-            rclear<NWT>(run, (uint32_t)n);
-            imaging += 1;
+            row((uint32_t)n)->since = 0;                          // every earlier attack now predates last_reimaging
+            rclear<WT>(m[M_INST], (uint32_t)n);
+            if (privilege((uint32_t)n)) { set_privilege((uint32_t)n, 0u); owned -= 1; }   // privilege NoAccess; tags stay
+            rclear<WT>(m[M_RUN], (uint32_t)n);
+            rset<WT>(fresh, (uint32_t)n);
+            dirty |= (1u << M_INST) | (1u << M_RUN);
         }
     }
 };
 
 // PHASE 0: whole step.  PHASE 1: attacker's action only (raw reward parked in S.pending).
 // PHASE 2: defender, goals, outputs, auto-reset (after the observation kernels ran).
-// NWT: node-mask words held in registers (1, 2 or 4).  TOPO_LDS: topology tables staged in LDS.
-template <int PHASE, int NWT, bool TOPO_LDS>
+// WT: words per set held in registers (1, 2 or 4; >= NW, SW, TW).  TOPO_LDS: topology tables staged in LDS.
+template <int PHASE, int WT, bool TOPO_LDS>
 __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, StepCfg C, StepIO io) {
     extern __shared__ uint4 topo_lds[];
+#ifdef MCBS_DIAG
+    unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); st_[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define STAMP_NOWAIT(i) do { __builtin_amdgcn_sched_barrier(0); st_[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define STAMP(i)
+#define STAMP_NOWAIT(i)
+#endif
+    STAMP_NOWAIT(0);
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = e < S.E;
     const uint32_t ec = active ? e : 0u;                // clamp so inactive lanes read valid memory and take no branch
+    const bool has_def = C.defender_kind != MCBS_DEFENDER_NONE;
 
     // ---------------- level 1: loads whose addresses depend on the env index only ----------------
     uint8_t* body = S.body + (size_t)ec * S.body_stride;
@@ -295,16 +300,22 @@ __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, StepCfg C
         chead0 = *reinterpret_cast<const uint4*>(body + S.off_cred);
         chead1 = *reinterpret_cast<const uint4*>(body + S.off_cred + 16);
     }
-    uint64_t inst0[NWT], run0[NWT];
+    uint64_t m0[M_COUNT][WT];
 #pragma unroll
-    for (int w = 0; w < NWT; ++w) {
-        const bool have = (uint32_t)w < S.NW;
-        inst0[w] = have ? S.m_inst[(size_t)w * S.E + ec] : 0ull;
-        run0[w] = have ? S.m_run[(size_t)w * S.E + ec] : 0ull;
+    for (int k = 0; k < M_COUNT; ++k) {
+        const uint32_t words = k == M_GATH ? S.SW : (k == M_CACH ? S.TW : S.NW);
+        const bool wanted = PHASE != 2 || (k != M_GATH && k != M_CACH && k != M_DISC && k != M_EVER);
+#pragma unroll
+        for (int w = 0; w < WT; ++w) m0[k][w] = (wanted && (uint32_t)w < words) ? S.mask[k][(uint32_t)w * S.E + ec] : 0ull;
     }
     double2 h1 = make_double2(0.0, 0.0);
-    if (PHASE != 1) h1 = S.h1[ec];
+    uint32_t episode = 0;
+    if (PHASE != 1) {
+        h1 = S.h1[ec];
+        if (has_def && C.rng_kind == MCBS_RNG_PHILOX) episode = S.episode[ec];
+    }
 
+    STAMP_NOWAIT(1);   // level-1 loads issued
     const uint8_t* tb = T.base;
     if (TOPO_LDS) {                                     // cooperative copy of the topology tables, 16 bytes per lane
         const uint4* src = reinterpret_cast<const uint4*>(T.base);
@@ -313,6 +324,7 @@ __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, StepCfg C
         tb = reinterpret_cast<const uint8_t*>(topo_lds);
     }
 
+    STAMP(2);          // level-1 loads and the LDS copy have landed
     bool need_reset = false;
     uint32_t step = h0.x, flags = h0.y;
     if (active && (flags & (F_DONE | F_TRUNC))) {
@@ -327,10 +339,18 @@ __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, StepCfg C
             if (io.raw_reward) io.raw_reward[e] = 0.0f;
         }
     } else if (active) {
-        Lane<NWT> ln{S, C, tb, e, body, h0.z & 0xFFFFu, h0.z >> 16, h0.w & 0xFFFFu, h0.w >> 16, {}, {}, 0ull, 0u, 0u, 0u, false,
-                     0.0, MCBS_OUT_NONE, 0, 0, 0};
+        Lane<WT> ln{S, C, tb, e, body, h0.z & 0xFFFFu, h0.z >> 16, h0.w & 0xFFFFu, h0.w >> 16, {}, 0u, 0ull, 0u, 0u, 0u, false,
+                    0.0, MCBS_OUT_NONE, 0, 0, 0};
 #pragma unroll
-        for (int w = 0; w < NWT; ++w) { ln.inst[w] = inst0[w]; ln.run[w] = run0[w]; }
+        for (int k = 0; k < M_COUNT; ++k)
+#pragma unroll
+            for (int w = 0; w < WT; ++w) ln.m[k][w] = m0[k][w];
+        // level 2 (needs the header): this defender tick's ring slot
+        uint64_t back[WT];
+#pragma unroll
+        for (int w = 0; w < WT; ++w)
+            back[w] = (PHASE != 1 && has_def && (uint32_t)w < S.NW) ? S.ring[((ln.dclk & 15u) * S.NW + (uint32_t)w) * S.E + e] : 0ull;
+
         bool oob = false;
         if (PHASE != 2) {
             // ---------------- __execute_action (cyberbattle_env.py:707-751) ----------------
@@ -355,9 +375,10 @@ __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, StepCfg C
                 // ---------------- level 2: the target row ----------------
                 const Row* rp = ln.row(tgt);
                 const uint4 r0 = *reinterpret_cast<const uint4*>(rp);
-                ln.misc = rp->misc;
+                ln.tags = rp->tags;
                 ln.props = (uint64_t)r0.x | ((uint64_t)r0.y << 32);
                 ln.ever = r0.z; ln.since = r0.w;
+                STAMP(3);  // row landed
                 if (kind == 2) {
                     uint32_t triple;
                     if (a4i < 16) {
@@ -365,14 +386,15 @@ __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, StepCfg C
                         triple = (d >> (16u * ((uint32_t)a4i & 1u))) & 0xFFFFu;
                     } else triple = ln.cred_list()[a4i];
                     ln.connect(src, tgt, (uint32_t)a3, triple);
-                } else if (!rget<NWT>(ln.inst, src)) ln.done_with(-1.0, MCBS_OUT_NONE);          // INVALID_ACTION
+                } else if (!rget<WT>(ln.m[M_INST], src)) ln.done_with(-1.0, MCBS_OUT_NONE);       // INVALID_ACTION
                 else ln.process_outcome(tgt, kind == 0 ? (uint32_t)a2 : C.L + (uint32_t)a3, kind == 0 ? -20.0 : -50.0);
                 if (ln.row_dirty) {
                     Row* wp = ln.row(tgt);
                     *reinterpret_cast<uint4*>(wp) = make_uint4((uint32_t)ln.props, (uint32_t)(ln.props >> 32), ln.ever, ln.since);
-                    wp->misc = ln.misc;
+                    wp->tags = ln.tags;
                 }
             }
+            STAMP(4);      // attacker logic and row store done
             if (oob) { ln.raw = 0.0; ln.okind = MCBS_OUT_NONE; ln.olevel = 0; ln.new_nodes = 0; ln.new_creds = 0; }
             flags = (oob ? F_OOB : 0u) | ((uint32_t)ln.okind << F_KIND_SHIFT) | ((uint32_t)ln.olevel << F_LEVEL_SHIFT) |
                     ((uint32_t)ln.new_nodes << F_NEWNODES_SHIFT) | ((uint32_t)ln.new_creds << F_NEWCREDS_SHIFT);
@@ -382,15 +404,21 @@ __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, StepCfg C
         }
         if (PHASE == 1) {
             S.pending[e] = ln.raw;
-            S.h0[e] = make_uint4(step, flags, ln.n_disc | (ln.n_creds << 16), ln.owned | (ln.imaging << 16));
+            S.h0[e] = make_uint4(step, flags, ln.n_disc | (ln.n_creds << 16), ln.owned | (ln.dclk << 16));
         } else {
             double reward = 0.0;
             bool done = false;
             if (!oob) {
-                const bool has_def = C.defender_kind != MCBS_DEFENDER_NONE;
                 if (has_def) {
-                    h1.y = ln.defender_tick();
-                    ln.defender_scan(step, io);
+                    uint64_t fresh[WT];
+#pragma unroll
+                    for (int w = 0; w < WT; ++w) fresh[w] = 0ull;
+                    h1.y = ln.defender_tick(back);
+                    ln.defender_scan(step, episode, io, fresh);
+#pragma unroll
+                    for (int w = 0; w < WT; ++w)       // the slot now holds the nodes re-imaged at this tick (released 16 ticks on)
+                        if ((uint32_t)w < S.NW && fresh[w] != back[w]) S.ring[((ln.dclk & 15u) * S.NW + (uint32_t)w) * S.E + e] = fresh[w];
+                    ln.dclk = (ln.dclk + 1u) & 0xFFFFu;
                 }
                 // goals (env.py:1080-1116) on the state AFTER the defender acted, availability from BEFORE its scan
                 bool attacker_goal = C.has_attacker_goal != 0;
@@ -418,19 +446,22 @@ __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, StepCfg C
             if ((done || trunc) && C.auto_reset) need_reset = true;
             else {
                 flags |= (done ? F_DONE : 0u) | (trunc ? F_TRUNC : 0u);
-                S.h0[e] = make_uint4(step, flags, ln.n_disc | (ln.n_creds << 16), ln.owned | (ln.imaging << 16));
+                S.h0[e] = make_uint4(step, flags, ln.n_disc | (ln.n_creds << 16), ln.owned | (ln.dclk << 16));
                 S.h1[e] = h1;
             }
         }
-        if (!need_reset) {
+        if (!need_reset && ln.dirty) {
 #pragma unroll
-            for (int w = 0; w < NWT; ++w) {
-                if ((uint32_t)w >= S.NW) break;
-                if (ln.inst[w] != inst0[w]) S.m_inst[(size_t)w * S.E + e] = ln.inst[w];
-                if (ln.run[w] != run0[w]) S.m_run[(size_t)w * S.E + e] = ln.run[w];
+            for (int k = 0; k < M_COUNT; ++k) {
+                if (!((ln.dirty >> k) & 1u)) continue;
+                const uint32_t words = k == M_GATH ? S.SW : (k == M_CACH ? S.TW : S.NW);
+#pragma unroll
+                for (int w = 0; w < WT; ++w)
+                    if ((uint32_t)w < words && ln.m[k][w] != m0[k][w]) S.mask[k][(uint32_t)w * S.E + e] = ln.m[k][w];
             }
         }
     }
+    STAMP(5);              // all stores of the step retired
     if (PHASE != 1) {
         // Envs that just ended are re-initialised by the whole wavefront: ballot the lanes that need it, then all
         // 64 lanes copy the reset image of one env at a time with 16-byte accesses (coalesced), instead of one
@@ -440,10 +471,10 @@ __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, StepCfg C
             __threadfence_block();   // the owner lane's row stores must land before other lanes overwrite them
             const uint32_t lane = threadIdx.x & 63u;
             const uint32_t wave_base = e - lane;
-            uint64_t m = rm;
-            while (m) {
-                const uint32_t l = (uint32_t)__builtin_ctzll(m);
-                m &= m - 1;
+            uint64_t mm = rm;
+            while (mm) {
+                const uint32_t l = (uint32_t)__builtin_ctzll(mm);
+                mm &= mm - 1;
                 uint8_t* dst = S.body + (size_t)(wave_base + l) * S.body_stride;
                 for (uint32_t off = lane * 16u; off < S.body_stride; off += 64u * 16u)
                     *reinterpret_cast<uint4*>(dst + off) = *reinterpret_cast<const uint4*>(S.init_body + off);
@@ -451,6 +482,14 @@ __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, StepCfg C
             if (need_reset) reset_header(S, T, e, S.episode[e] + 1u);
         }
     }
+#ifdef MCBS_DIAG
+    STAMP(6);
+    if (io.stamps && (threadIdx.x & 63u) == 0) {
+        unsigned long long* o = io.stamps + (size_t)(e >> 6) * 8;
+        for (int i = 0; i < 7; ++i) o[i] = st_[i];
+        o[7] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 } // namespace mcbs
