@@ -1,0 +1,78 @@
+"""CPU-side checks of the product's native library: it loads, exports every entry point include/mcbs.h declares,
+rejects malformed input through the C ABI without touching a GPU, and the Python layer refuses to run without it
+(no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from marlon_amd import engine, flatten
+from marlon_amd._abi import BatchCfg
+from marlon_amd.samples import chainpattern
+
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def declared_functions():
+    text = open(os.path.join(REPO, "include", "mcbs.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mcbs_[a-z_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = engine.load_library()
+    names = declared_functions()
+    assert len(names) >= 18 and set(names) == set(engine.EXPORTS)
+    for n in names:
+        assert hasattr(lib, n), f"libmcbs.so does not export {n}"
+    assert lib.mcbs_abi_version() == 1
+
+
+def test_abi_struct_sizes_match_header():
+    # compiled against include/mcbs.h by gcc in tests/test_oracle_*: here only the Python mirrors
+    assert C.sizeof(BatchCfg) == 136
+    assert flatten.HEADER_DT.itemsize == 192 and flatten.NODE_DT.itemsize == 64 and flatten.SLOT_DT.itemsize == 32
+
+
+def test_topology_create_rejects_malformed_blobs_without_gpu():
+    lib = engine.load_library()
+    out = C.c_void_p()
+    junk = np.zeros(64, np.uint8)
+    assert lib.mcbs_topology_create(junk.ctypes.data, junk.size, 0, C.byref(out)) == -1
+    assert b"too small" in lib.mcbs_last_error()
+    blob = np.frombuffer(flatten.flatten(chainpattern.new_environment(4)).blob, np.uint8).copy()
+    bad = blob.copy()
+    bad[0] ^= 0xFF
+    assert lib.mcbs_topology_create(bad.ctypes.data, bad.size, 0, C.byref(out)) == -1
+    assert b"magic" in lib.mcbs_last_error()
+    bad = blob.copy()
+    bad[:192].view(flatten.HEADER_DT)[0]["n_nodes"] = 300
+    assert lib.mcbs_topology_create(bad.ctypes.data, bad.size, 0, C.byref(out)) == -2       # MCBS_ELIMIT
+    bad = blob.copy()
+    hdr = bad[:192].view(flatten.HEADER_DT)[0]
+    bad[int(hdr["off_slot_of"])] = 200                                                     # slot index out of range
+    assert lib.mcbs_topology_create(bad.ctypes.data, bad.size, 0, C.byref(out)) == -1
+    assert lib.mcbs_step(None, None, None, None, None, None) == -1                          # null arguments
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    with pytest.raises(engine.NativeLibraryMissing, match="no CPU fallback"):
+        engine.load_library(str(tmp_path / "libmcbs.so"))
+
+
+def test_product_never_imports_the_oracle():
+    for root, _, files in os.walk(os.path.join(REPO, "marlon_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(root, f)).read()
+                assert "from oracle" not in src and "import oracle" not in src and "cbs_oracle" not in src, f
+
+
+@pytest.mark.skipif(__import__("torch").cuda.is_available(), reason="only meaningful on a GPU-less host")
+def test_engine_refuses_to_run_without_gpu():
+    from marlon_amd._abi import EnvSpec
+    topo = flatten.flatten(chainpattern.new_environment(4))
+    with pytest.raises(engine.McbsError, match="no CPU fallback"):
+        engine.BatchEngine(topo, EnvSpec(n_envs=4, maximum_node_count=6, maximum_total_credentials=6))
