@@ -162,6 +162,8 @@ typedef struct mcbs_triple { /* 8 bytes */
 
 #define MCBS_RNG_PHILOX 0 /* draw i of a step = half (i&1) of Philox4x32-10(key = (seed lo, seed hi ^ env id hi),
                              ctr = (global env id lo, episode, step_count, i>>1)), 53-bit doubles (hi>>5, lo>>6) */
+#define MCBS_ACTION_SKIP 3
+
 #define MCBS_RNG_TAPE   1 /* draws read from a caller tape (parity against the reference's global RNGs) */
 
 typedef struct mcbs_batch_cfg {
@@ -246,6 +248,9 @@ int  mcbs_reset(mcbs_batch*, const uint8_t* env_mask, void* stream);
  *     kind 0 local_vulnerability  (source, vuln)              -- action dict order of env.py:540-559
  *     kind 1 remote_vulnerability (source, target, vuln)
  *     kind 2 connect              (source, target, port, credential index)
+ *     kind 3 skip                 the env is not stepped at all (no step count, no defender, state untouched);
+ *                                 reward 0, terminated 0.  This is how marlon's AttackerEnvWrapper handles an
+ *                                 action whose node index is not discovered yet (attack_wrapper.py:286-308).
  * reward: device float [E]; terminated: device uint8 [E]; info may be NULL.
  * An env that is done and not auto-reset is left untouched (reward 0, terminated 1): the
  * single-env facade raises the reference's RuntimeError (env.py:1146-1147) on the host. */
@@ -262,6 +267,15 @@ int  mcbs_step_observe(mcbs_batch*, const int32_t* actions, float* reward, uint8
  * mcbs_reset; otherwise the state-aggregated fields with the per-step flags of the last action. */
 int  mcbs_observe(mcbs_batch*, const mcbs_obs_buffers* obs, void* stream);
 
+/* mcbs_observe restricted to the envs whose byte in the device array env_mask[E] is non-zero; the buffers of the other
+ * envs are left as they are (VecEnv auto-reset: only the envs that were just reset get a fresh observation). */
+int  mcbs_observe_masked(mcbs_batch*, const mcbs_obs_buffers* obs, const uint8_t* env_mask, void* stream);
+
+/* CyberBattleEnv.compute_action_mask (env.py:679-683): the three masks (and/or mask_discrete) of the CURRENT state,
+ * whatever the last step was (mcbs_observe returns all-zero masks after an out-of-bound step, like the reference's
+ * blank observation).  Only the mask_* members of the buffers are used. */
+int  mcbs_action_mask(mcbs_batch*, const mcbs_obs_buffers* masks, void* stream);
+
 /* StepInfo fields without stepping. */
 int  mcbs_step_info(mcbs_batch*, const mcbs_info_buffers* info, void* stream);
 
@@ -270,6 +284,16 @@ int  mcbs_step_info(mcbs_batch*, const mcbs_info_buffers* info, void* stream);
  * component uniformly in its bound, invalid actions included.  Philox stream separate from the
  * defender's.  actions_out: device int32 [E,5]. */
 int  mcbs_sample_actions(mcbs_batch*, int32_t valid, uint64_t seed, uint64_t step, int32_t* actions_out, void* stream);
+
+/* marlon's attacker action encodings -> engine action rows, on the device.
+ *   multidiscrete: int64 [E,10] = AttackerEnvWrapper's MultiDiscrete (attack_wrapper.py:206-227,255-267):
+ *                  [kind, l_src, l_vuln, r_src, r_tgt, r_vuln, c_src, c_tgt, c_port, c_cred]; or NULL
+ *   discrete:      int64 [E]    = MaskedDiscreteAttackerWrapper's Discrete index (action_masking.py:112-142):
+ *                  connect block ((src*N+tgt)*P+port)*C+cred, then local src*L+vuln, then remote (src*N+tgt)*R+vuln
+ * Exactly one of the two is non-NULL.  An action whose source / target index is not below the env's discovered-node
+ * count is turned into a skip row and flagged in invalid[E] (attack_wrapper.py:236-253,286-308). */
+int  mcbs_decode_attacker_actions(mcbs_batch*, const int64_t* multidiscrete, const int64_t* discrete,
+                                  int32_t* actions_out, uint8_t* invalid_out, void* stream);
 
 /* Defender draw tape for MCBS_RNG_TAPE: device double [E, draws_per_step] consumed by the next
  * step (scan draws first, then detection draws in consumption order). */

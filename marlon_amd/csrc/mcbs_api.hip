@@ -348,10 +348,12 @@ extern "C" int mcbs_step(mcbs_batch* b, const int32_t* actions, float* reward, u
     return timing_end(b, st, slot);
 }
 
-static int launch_masks(mcbs_batch* b, const mcbs_obs_buffers* o, hipStream_t st);
+static int launch_masks(mcbs_batch* b, const mcbs_obs_buffers* o, hipStream_t st, const uint8_t* env_mask, bool masks_only);
 
-static int launch_obs(mcbs_batch* b, const mcbs_obs_buffers* o, hipStream_t st) {
+static int launch_obs(mcbs_batch* b, const mcbs_obs_buffers* o, hipStream_t st, bool masks_only = false, const uint8_t* env_mask = nullptr) {
     ObsIO O{};
+    O.masks_only = masks_only ? 1u : 0u;
+    O.env_mask = env_mask;
     O.scalars = o->scalars; O.leaked = o->leaked_credentials; O.cache_matrix = o->credential_cache_matrix;
     O.props = o->discovered_nodes_properties; O.priv = o->nodes_privilegelevel; O.mask_local = o->mask_local;
     O.mask_remote = o->mask_remote; O.mask_connect = o->mask_connect; O.mask_discrete = o->mask_discrete;
@@ -359,11 +361,11 @@ static int launch_obs(mcbs_batch* b, const mcbs_obs_buffers* o, hipStream_t st) 
     hipLaunchKernelGGL(obs_small_kernel, dim3((b->S.E + 3) / 4), dim3(256), 0, st, b->S, b->T, b->C, O, b->digest);
     int rc = launch_ok("obs_small");
     if (rc) return rc;
-    return launch_masks(b, o, st);
+    return launch_masks(b, o, st, env_mask, masks_only);
 }
 
 template <int REGION>
-static int launch_region(mcbs_batch* b, int8_t* dst, size_t env_stride, size_t region_off, size_t len, hipStream_t st) {
+static int launch_region(mcbs_batch* b, int8_t* dst, size_t env_stride, size_t region_off, size_t len, hipStream_t st, const uint8_t* env_mask, bool masks_only) {
     const uint32_t Nm = b->cfg.maximum_node_count, Cm = b->cfg.maximum_total_credentials;
     const uintptr_t base = reinterpret_cast<uintptr_t>(dst) + region_off;
     int W = 1;
@@ -372,23 +374,23 @@ static int launch_region(mcbs_batch* b, int8_t* dst, size_t env_stride, size_t r
     const size_t chunks = (len + W - 1) / W;
     const dim3 grid(b->S.E, (unsigned)((chunks + 255) / 256));
     if (grid.y > 65535u) return fail(MCBS_ELIMIT, "mask region too large for one launch");
-    if (W == 16) hipLaunchKernelGGL((mask_kernel<16, REGION>), grid, dim3(256), 0, st, b->S, b->T, b->C, b->digest, dst, env_stride, region_off, Nm, Cm);
-    else if (W == 4) hipLaunchKernelGGL((mask_kernel<4, REGION>), grid, dim3(256), 0, st, b->S, b->T, b->C, b->digest, dst, env_stride, region_off, Nm, Cm);
-    else hipLaunchKernelGGL((mask_kernel<1, REGION>), grid, dim3(256), 0, st, b->S, b->T, b->C, b->digest, dst, env_stride, region_off, Nm, Cm);
+    if (W == 16) hipLaunchKernelGGL((mask_kernel<16, REGION>), grid, dim3(256), 0, st, b->S, b->T, b->C, b->digest, dst, env_stride, region_off, Nm, Cm, env_mask, masks_only ? 0u : 1u);
+    else if (W == 4) hipLaunchKernelGGL((mask_kernel<4, REGION>), grid, dim3(256), 0, st, b->S, b->T, b->C, b->digest, dst, env_stride, region_off, Nm, Cm, env_mask, masks_only ? 0u : 1u);
+    else hipLaunchKernelGGL((mask_kernel<1, REGION>), grid, dim3(256), 0, st, b->S, b->T, b->C, b->digest, dst, env_stride, region_off, Nm, Cm, env_mask, masks_only ? 0u : 1u);
     return launch_ok("mask");
 }
 
-static int launch_masks(mcbs_batch* b, const mcbs_obs_buffers* o, hipStream_t st) {
+static int launch_masks(mcbs_batch* b, const mcbs_obs_buffers* o, hipStream_t st, const uint8_t* env_mask, bool masks_only) {
     const size_t Nm = b->cfg.maximum_node_count, Cm = b->cfg.maximum_total_credentials;
     const size_t M = Nm * Nm * b->C.P * Cm, ML = Nm * b->C.L, MR = Nm * Nm * b->C.R;
     int rc = MCBS_OK;
-    if (o->mask_connect && (rc = launch_region<0>(b, o->mask_connect, M, 0, M, st))) return rc;
-    if (o->mask_remote && (rc = launch_region<1>(b, o->mask_remote, MR, 0, MR, st))) return rc;
+    if (o->mask_connect && (rc = launch_region<0>(b, o->mask_connect, M, 0, M, st, env_mask, masks_only))) return rc;
+    if (o->mask_remote && (rc = launch_region<1>(b, o->mask_remote, MR, 0, MR, st, env_mask, masks_only))) return rc;
     if (o->mask_discrete) {   // connect | local | remote (action_masking.py:96-110)
         const size_t D = M + ML + MR;
-        if ((rc = launch_region<0>(b, o->mask_discrete, D, 0, M, st))) return rc;
-        if ((rc = launch_region<2>(b, o->mask_discrete, D, M, ML, st))) return rc;
-        if ((rc = launch_region<1>(b, o->mask_discrete, D, M + ML, MR, st))) return rc;
+        if ((rc = launch_region<0>(b, o->mask_discrete, D, 0, M, st, env_mask, masks_only))) return rc;
+        if ((rc = launch_region<2>(b, o->mask_discrete, D, M, ML, st, env_mask, masks_only))) return rc;
+        if ((rc = launch_region<1>(b, o->mask_discrete, D, M + ML, MR, st, env_mask, masks_only))) return rc;
     }
     return rc;
 }
@@ -396,6 +398,16 @@ static int launch_masks(mcbs_batch* b, const mcbs_obs_buffers* o, hipStream_t st
 extern "C" int mcbs_observe(mcbs_batch* b, const mcbs_obs_buffers* obs, void* stream) {
     if (!b || !obs) return fail(MCBS_EINVAL, "null argument");
     return launch_obs(b, obs, (hipStream_t)stream);
+}
+
+extern "C" int mcbs_observe_masked(mcbs_batch* b, const mcbs_obs_buffers* obs, const uint8_t* env_mask, void* stream) {
+    if (!b || !obs) return fail(MCBS_EINVAL, "null argument");
+    return launch_obs(b, obs, (hipStream_t)stream, false, env_mask);
+}
+
+extern "C" int mcbs_action_mask(mcbs_batch* b, const mcbs_obs_buffers* masks, void* stream) {
+    if (!b || !masks) return fail(MCBS_EINVAL, "null argument");
+    return launch_obs(b, masks, (hipStream_t)stream, true);
 }
 
 extern "C" int mcbs_step_observe(mcbs_batch* b, const int32_t* actions, float* reward, uint8_t* terminated,
@@ -423,6 +435,14 @@ extern "C" int mcbs_sample_actions(mcbs_batch* b, int32_t valid, uint64_t seed, 
     hipLaunchKernelGGL(sample_kernel, dim3((b->S.E + 127) / 128), dim3(128), 0, (hipStream_t)stream, b->S, b->T, b->C, (int)valid, seed, step,
                        b->cfg.maximum_node_count, b->cfg.maximum_total_credentials, actions_out);
     return launch_ok("sample");
+}
+
+extern "C" int mcbs_decode_attacker_actions(mcbs_batch* b, const int64_t* multidiscrete, const int64_t* discrete,
+                                            int32_t* actions_out, uint8_t* invalid_out, void* stream) {
+    if (!b || !actions_out || !invalid_out || (!multidiscrete == !discrete)) return fail(MCBS_EINVAL, "need exactly one action encoding and both outputs");
+    hipLaunchKernelGGL(decode_kernel, dim3((b->S.E + 255) / 256), dim3(256), 0, (hipStream_t)stream, b->S, b->C,
+                       b->cfg.maximum_node_count, b->cfg.maximum_total_credentials, multidiscrete, discrete, actions_out, invalid_out);
+    return launch_ok("decode");
 }
 
 // ------------------------------------------------------------------ state export / import (debug, synchronous)

@@ -100,4 +100,50 @@ __global__ __launch_bounds__(128) void sample_kernel(DevState S, Topo T, StepCfg
     o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = a[4];
 }
 
+// AttackerEnvWrapper.step's decode + out-of-range interception (attack_wrapper.py:255-308, :236-253) and
+// MaskedDiscreteAttackerWrapper._decode (action_masking.py:112-142), one lane per env.
+__global__ __launch_bounds__(256) void decode_kernel(DevState S, StepCfg C, uint32_t Nmax, uint32_t Cmax, const int64_t* md,
+                                                    const int64_t* discrete, int32_t* out, uint8_t* invalid) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= S.E) return;
+    const int64_t nd = (int64_t)(S.h0[e].z & 0xFFFFu);
+    int64_t kind, a = 0, b = 0, c = 0, d = 0;
+    if (md) {
+        // all ten components are read and the row is picked with selects: a three-way branch here was
+        // mis-structurised by ROCm 7.2's compiler (the kind >= 2 lanes kept uninitialised addresses)
+        const int64_t* v = md + (size_t)e * 10;
+        int64_t x[10];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) x[i] = v[i];
+        kind = x[0];
+        const bool k0 = kind == 0, k1 = kind == 1;
+        a = k0 ? x[1] : (k1 ? x[3] : x[6]);
+        b = k0 ? x[2] : (k1 ? x[4] : x[7]);
+        c = k0 ? 0 : (k1 ? x[5] : x[8]);
+        d = (k0 || k1) ? 0 : x[9];
+    } else {
+        const int64_t N = Nmax, P = C.P, Cm = Cmax, L = C.L, R = C.R;
+        const int64_t connect_size = N * N * P * Cm, local_size = N * L;
+        const int64_t idx = discrete[e];
+        const bool is_c = idx < connect_size, is_l = !is_c && idx < connect_size + local_size;     // selects, no branches (see above)
+        const int64_t rel = is_c ? idx : (is_l ? idx - connect_size : idx - connect_size - local_size);
+        const int64_t inner = is_c ? Cm : (is_l ? L : R);
+        const int64_t x0 = rel % inner, q = rel / inner;
+        const int64_t qp = q / P;
+        kind = is_c ? 2 : (is_l ? 0 : 1);
+        a = is_c ? qp / N : (is_l ? q : q / N);
+        b = is_c ? qp % N : (is_l ? x0 : q % N);
+        c = is_c ? q % P : (is_l ? 0 : x0);
+        d = is_c ? x0 : 0;
+    }
+    bool ok;                                               // _action_in_discovered_range
+    if (kind == 0) ok = a < nd;
+    else if (kind == 1 || kind == 2) ok = a < nd && b < nd;
+    else ok = false;
+    int32_t* o = out + (size_t)e * 5;
+    o[0] = ok ? (int32_t)kind : MCBS_ACTION_SKIP;
+    o[1] = (int32_t)a; o[2] = (int32_t)b; o[3] = (int32_t)c; o[4] = (int32_t)d;
+    invalid[e] = ok ? 0 : 1;
+}
+
 } // namespace mcbs

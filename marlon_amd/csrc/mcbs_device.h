@@ -22,6 +22,7 @@ namespace mcbs {
 
 // flags word (h0.y)
 constexpr uint32_t F_DONE = 1u, F_TRUNC = 2u, F_OOB = 4u;
+constexpr uint32_t F_SKIP = 8u;       // set by the attacker phase of a split step for a skip action, consumed by phase 2
 constexpr int F_KIND_SHIFT = 4;      // 4 bits  last outcome kind (MCBS_OUT_*)
 constexpr int F_LEVEL_SHIFT = 8;     // 2 bits  last escalation level
 constexpr int F_NEWNODES_SHIFT = 12; // 10 bits newly discovered nodes of the last action
@@ -89,6 +90,8 @@ struct ObsIO {
     int32_t* scalars; int32_t* leaked; int32_t* cache_matrix; int32_t* props; int32_t* priv;
     int8_t* mask_local; int8_t* mask_remote; int8_t* mask_connect; int8_t* mask_discrete;
     uint32_t Nmax, Cmax, K;
+    const uint8_t* env_mask; // optional [E]: only envs with a non-zero byte are written
+    uint32_t masks_only;   // compute_action_mask: ignore the out-of-bound flag, write only mask fields
 };
 
 // ------------------------------ Philox4x32-10 (Random123) ------------------------------

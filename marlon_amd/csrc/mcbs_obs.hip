@@ -30,10 +30,12 @@ __global__ __launch_bounds__(256) void obs_small_kernel(DevState S, Topo T, Step
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t e = blockIdx.x * 4u + wave;
     if (e >= S.E) return;                     // whole wavefront leaves together
+    if (O.env_mask && !O.env_mask[e]) return; // wave-uniform: one wavefront per env
     uint8_t* ext_of = ext_of_all[wave];
     const uint4 h0 = S.h0[e];
     const uint32_t flags = h0.y, n_disc = h0.z & 0xFFFFu, n_creds = h0.z >> 16;
-    const bool blank = (flags & F_OOB) != 0;
+    if (!O.masks_only && (flags & F_SKIP)) return;   // split step, skip action: the env's previous observation stands
+    const bool blank = !O.masks_only && (flags & F_OOB) != 0;
     const uint32_t kind = (flags >> F_KIND_SHIFT) & 0xFu, level = (flags >> F_LEVEL_SHIFT) & 3u;
     const uint32_t new_nodes = (flags >> F_NEWNODES_SHIFT) & 0x3FFu, new_creds = (flags >> F_NEWCREDS_SHIFT) & 0x3FFu;
     const uint8_t* body = S.body + (size_t)e * S.body_stride;
@@ -69,6 +71,7 @@ __global__ __launch_bounds__(256) void obs_small_kernel(DevState S, Topo T, Step
         digest[e] = d;
     }
 
+    if (O.masks_only) goto local_mask;
     if (O.scalars && lane < 7) {
         int32_t v = 0;
         if (lane == 6) v = (int32_t)n_disc;
@@ -128,6 +131,7 @@ __global__ __launch_bounds__(256) void obs_small_kernel(DevState S, Topo T, Step
             out[i] = v;
         }
     }
+local_mask:
     if (O.mask_local) {
         int8_t* out = O.mask_local + (size_t)e * Nm * L;
         for (uint32_t idx = lane; idx < Nm * L; idx += 64u) {
@@ -142,8 +146,11 @@ __global__ __launch_bounds__(256) void obs_small_kernel(DevState S, Topo T, Step
 // REGION 0: connect [N,N,P,C]   1: remote [N,N,R]   2: local [N,L]
 template <int W, int REGION>
 __global__ __launch_bounds__(256) void mask_kernel(DevState S, Topo T, StepCfg C, const ObsDigest* digest, int8_t* dst,
-                                                   size_t env_stride, size_t region_off, uint32_t Nm, uint32_t Cm) {
+                                                   size_t env_stride, size_t region_off, uint32_t Nm, uint32_t Cm, const uint8_t* env_mask,
+                                                   uint32_t skip_flagged) {
     const uint32_t e = blockIdx.x;
+    if (env_mask && !env_mask[e]) return;      // uniform per workgroup
+    if (skip_flagged && (S.h0[e].y & F_SKIP)) return;
     const uint32_t k = blockIdx.y * blockDim.x + threadIdx.x;
     const uint32_t inner = REGION == 0 ? C.P * Cm : (REGION == 1 ? C.R : C.L);
     const uint32_t len = REGION == 2 ? Nm * inner : Nm * Nm * inner;
@@ -187,9 +194,9 @@ __global__ __launch_bounds__(256) void mask_kernel(DevState S, Topo T, StepCfg C
 }
 
 #define MCBS_INST(W) \
-    template __global__ void mask_kernel<W, 0>(DevState, Topo, StepCfg, const ObsDigest*, int8_t*, size_t, size_t, uint32_t, uint32_t); \
-    template __global__ void mask_kernel<W, 1>(DevState, Topo, StepCfg, const ObsDigest*, int8_t*, size_t, size_t, uint32_t, uint32_t); \
-    template __global__ void mask_kernel<W, 2>(DevState, Topo, StepCfg, const ObsDigest*, int8_t*, size_t, size_t, uint32_t, uint32_t);
+    template __global__ void mask_kernel<W, 0>(DevState, Topo, StepCfg, const ObsDigest*, int8_t*, size_t, size_t, uint32_t, uint32_t, const uint8_t*, uint32_t); \
+    template __global__ void mask_kernel<W, 1>(DevState, Topo, StepCfg, const ObsDigest*, int8_t*, size_t, size_t, uint32_t, uint32_t, const uint8_t*, uint32_t); \
+    template __global__ void mask_kernel<W, 2>(DevState, Topo, StepCfg, const ObsDigest*, int8_t*, size_t, size_t, uint32_t, uint32_t, const uint8_t*, uint32_t);
 MCBS_INST(16)
 MCBS_INST(4)
 MCBS_INST(1)

@@ -327,11 +327,18 @@ __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, StepCfg C
     STAMP(2);          // level-1 loads and the LDS copy have landed
     bool need_reset = false;
     uint32_t step = h0.x, flags = h0.y;
-    if (active && (flags & (F_DONE | F_TRUNC))) {
+    // finished envs and skip actions (MCBS_ACTION_SKIP) leave the env untouched
+    const bool skip_env = (PHASE != 2 && (int)a03.x == MCBS_ACTION_SKIP) || (PHASE == 2 && (flags & F_SKIP));
+    if (active && PHASE == 1 && !(flags & (F_DONE | F_TRUNC))) {
+        const uint32_t nf = skip_env ? (flags | F_SKIP) : (flags & ~F_SKIP);
+        if (skip_env && nf != flags) S.h0[e].y = nf;
+    }
+    if (active && PHASE == 2 && (flags & F_SKIP)) S.h0[e].y = flags & ~F_SKIP;
+    if (active && ((flags & (F_DONE | F_TRUNC)) || skip_env)) {
         // step after done: the reference raises RuntimeError (env.py:1146-1147); the batch leaves the env untouched
         if (PHASE != 1) {
             io.reward[e] = 0.0f;
-            io.terminated[e] = (uint8_t)(flags & F_DONE);
+            io.terminated[e] = (uint8_t)((flags & F_DONE) ? 1 : 0);
             if (io.truncated) io.truncated[e] = (uint8_t)((flags & F_TRUNC) ? 1 : 0);
             if (io.availability) io.availability[e] = h1.y;
             if (io.step_count) io.step_count[e] = (int32_t)step;

@@ -21,8 +21,8 @@ LIB_PATH = os.path.join(_HERE, "libmcbs.so")
 
 EXPORTS = [
     "mcbs_last_error", "mcbs_abi_version", "mcbs_topology_create", "mcbs_topology_destroy", "mcbs_batch_create",
-    "mcbs_batch_destroy", "mcbs_reset", "mcbs_step", "mcbs_step_observe", "mcbs_observe", "mcbs_step_info",
-    "mcbs_sample_actions", "mcbs_set_draw_tape", "mcbs_state_record_bytes", "mcbs_get_state", "mcbs_set_state",
+    "mcbs_batch_destroy", "mcbs_reset", "mcbs_step", "mcbs_step_observe", "mcbs_observe", "mcbs_observe_masked", "mcbs_action_mask", "mcbs_step_info",
+    "mcbs_sample_actions", "mcbs_decode_attacker_actions", "mcbs_set_draw_tape", "mcbs_state_record_bytes", "mcbs_get_state", "mcbs_set_state",
     "mcbs_timing_enable", "mcbs_timing_read",
 ]
 
@@ -59,8 +59,11 @@ def load_library(path: Optional[str] = None):
     lib.mcbs_step_observe.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(InfoBuffers),
                                       C.POINTER(ObsBuffers), C.c_void_p]
     lib.mcbs_observe.argtypes = [C.c_void_p, C.POINTER(ObsBuffers), C.c_void_p]
+    lib.mcbs_observe_masked.argtypes = [C.c_void_p, C.POINTER(ObsBuffers), C.c_void_p, C.c_void_p]
+    lib.mcbs_action_mask.argtypes = [C.c_void_p, C.POINTER(ObsBuffers), C.c_void_p]
     lib.mcbs_step_info.argtypes = [C.c_void_p, C.POINTER(InfoBuffers), C.c_void_p]
     lib.mcbs_sample_actions.argtypes = [C.c_void_p, C.c_int32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
+    lib.mcbs_decode_attacker_actions.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.mcbs_set_draw_tape.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
     lib.mcbs_state_record_bytes.restype = C.c_size_t
     lib.mcbs_state_record_bytes.argtypes = [C.c_void_p]
@@ -202,10 +205,20 @@ class BatchEngine:
                                                     C.byref(self._info_struct), C.byref(b), self._stream()), "mcbs_step_observe")
         return self.reward, self.terminated
 
-    def observe(self, obs: dict) -> dict:
+    def observe(self, obs: dict, env_mask=None) -> dict:
         b = self._obs_struct(obs)
-        _check(self.lib, self.lib.mcbs_observe(self._h, C.byref(b), self._stream()), "mcbs_observe")
+        if env_mask is None:
+            _check(self.lib, self.lib.mcbs_observe(self._h, C.byref(b), self._stream()), "mcbs_observe")
+        else:
+            env_mask = env_mask.to(device=self.device, dtype=self.torch.uint8).contiguous()
+            _check(self.lib, self.lib.mcbs_observe_masked(self._h, C.byref(b), env_mask.data_ptr(), self._stream()), "mcbs_observe_masked")
         return obs
+
+    def action_mask(self, masks: dict) -> dict:
+        """compute_action_mask for every env: fills the mask_* tensors given (current state, never blank)."""
+        b = self._obs_struct({k: v for k, v in masks.items() if k.startswith("mask_")})
+        _check(self.lib, self.lib.mcbs_action_mask(self._h, C.byref(b), self._stream()), "mcbs_action_mask")
+        return masks
 
     def step_info(self) -> dict:
         _check(self.lib, self.lib.mcbs_step_info(self._h, C.byref(self._info_struct), self._stream()), "mcbs_step_info")
@@ -218,6 +231,26 @@ class BatchEngine:
         _check(self.lib, self.lib.mcbs_sample_actions(self._h, int(bool(valid)), int(seed), int(step), out.data_ptr(), self._stream()),
                "mcbs_sample_actions")
         return out
+
+    def decode_attacker_actions(self, multidiscrete=None, discrete=None, actions_out=None, invalid_out=None):
+        """marlon's MultiDiscrete(10) / Discrete attacker actions -> engine rows [E,5] + invalid flags [E] (device)."""
+        t = self.torch
+        if (multidiscrete is None) == (discrete is None):
+            raise ValueError("give exactly one of multidiscrete / discrete")
+        src = multidiscrete if multidiscrete is not None else discrete
+        src = src if isinstance(src, t.Tensor) else t.as_tensor(np.asarray(src))
+        src = src.to(device=self.device, dtype=t.int64).contiguous()
+        want = (self.E, 10) if multidiscrete is not None else (self.E,)
+        if tuple(src.shape) != want:
+            raise ValueError(f"expected shape {want}, got {tuple(src.shape)}")
+        if actions_out is None:
+            actions_out = t.empty((self.E, 5), dtype=t.int32, device=self.device)
+        if invalid_out is None:
+            invalid_out = t.empty(self.E, dtype=t.uint8, device=self.device)
+        _check(self.lib, self.lib.mcbs_decode_attacker_actions(
+            self._h, src.data_ptr() if multidiscrete is not None else None, src.data_ptr() if discrete is not None else None,
+            actions_out.data_ptr(), invalid_out.data_ptr(), self._stream()), "mcbs_decode_attacker_actions")
+        return actions_out, invalid_out
 
     def get_state(self):
         rb = state_record_bytes(self.topo.n_nodes, self.spec.maximum_total_credentials)

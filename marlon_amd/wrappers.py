@@ -1,0 +1,139 @@
+"""Batched counterparts of marlon's attacker env wrappers.
+
+`AttackerVecEnv` is `AttackerEnvWrapper` (marlon/baseline_models/env_wrappers/attack_wrapper.py) for a whole batch
+of environments living on the GPU, with the Stable-Baselines3 `VecEnv` calling convention the reference reaches
+through `DummyVecEnv([...])` (marlon/baseline_models/ppo_multi/train_marl_multi.py:181-183):
+
+  * action: MultiDiscrete `[3, N, L, N, N, R, N, N, P, C]` rows `[kind, l_src, l_vuln, r_src, r_tgt, r_vuln, c_src,
+    c_tgt, c_port, c_cred]` (attack_wrapper.py:206-227) or, with `discrete=True`, the single Discrete index of
+    `MaskedDiscreteAttackerWrapper` (action_masking.py:30-142) — decoded on the device by `mcbs_decode_attacker_actions`;
+  * an action whose node index is not discovered yet does NOT step the env: the last observation is returned,
+    reward is `0 + invalid_action_reward_modifier`, `info["invalid_action"]` is set (attack_wrapper.py:286-308);
+  * observation: the flat dict of attack_wrapper.py:474-522, every value a device tensor with a leading env axis
+    (`scalars` also split into the seven named integer keys); `action_masks()` = action_masking.py:90-110;
+  * `timesteps` counts wrapper steps (invalid ones included) and truncates at `max_timesteps` (:346-352);
+  * finished envs are reset inside `step` like a VecEnv does; the observation that ended the episode is kept in
+    `terminal_observation` for the envs flagged in `dones`.
+
+All simulation work is in the HIP kernels; the few tensor expressions here are the wrapper's own bookkeeping
+(timestep counters, reward modifier).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+
+from ._abi import EnvSpec
+from .cyberbattle_env import (SCALAR_KEYS, AttackerGoal, DefenderConstraint, DefenderGoal, spec_from_kwargs)
+from .flatten import FlatTopology, flatten
+
+FLAT_FIELDS = ["scalars", "leaked_credentials", "credential_cache_matrix", "discovered_nodes_properties",
+               "nodes_privilegelevel", "mask_local", "mask_remote", "mask_connect", "mask_discrete"]
+
+
+class AttackerVecEnv:
+    def __init__(self, initial_environment, n_envs: int, maximum_total_credentials: int = 1000, maximum_node_count: int = 100,
+                 maximum_discoverable_credentials_per_action: int = 5, defender_agent=None,
+                 attacker_goal: Optional[AttackerGoal] = AttackerGoal(own_atleast_percent=1.0),
+                 defender_goal=DefenderGoal(eviction=True), defender_constraint=DefenderConstraint(maintain_sla=0.0),
+                 winning_reward=5000.0, losing_reward=0.0, max_timesteps: int = 2000, invalid_action_reward_modifier=-1,
+                 discrete: bool = False, auto_reset: bool = True, device: Optional[str] = None, seed: int = 0,
+                 env_id_base: int = 0, rng_kind: int = 0):
+        from .engine import BatchEngine
+        self.topo: FlatTopology = initial_environment if isinstance(initial_environment, FlatTopology) else flatten(initial_environment)
+        # the wrapper owns truncation and resets (its clock counts invalid actions too), so the engine's own are off
+        self.spec: EnvSpec = spec_from_kwargs(n_envs, maximum_total_credentials, maximum_node_count,
+                                              maximum_discoverable_credentials_per_action, defender_agent, attacker_goal,
+                                              defender_goal, defender_constraint, winning_reward, losing_reward,
+                                              auto_reset=False, max_episode_steps=0, seed=seed, env_id_base=env_id_base, rng_kind=rng_kind)
+        self.engine = BatchEngine(self.topo, self.spec, device=device)
+        t = self.torch = self.engine.torch
+        self.num_envs = n_envs
+        self.max_timesteps = int(max_timesteps)
+        self.invalid_action_reward_modifier = float(invalid_action_reward_modifier)
+        self.discrete = bool(discrete)
+        self.auto_reset = bool(auto_reset)
+        N, Cm = maximum_node_count, maximum_total_credentials
+        L, R, P = len(self.topo.local_vulnerabilities), len(self.topo.remote_vulnerabilities), len(self.topo.ports)
+        self.nvec = np.array([3, N, L, N, N, R, N, N, P, Cm], dtype=np.int64)                      # attack_wrapper.py:206-227
+        self.discrete_n = N * N * P * Cm + N * L + N * N * R                                         # action_masking.py:74-80
+        dev = self.engine.device
+        self._obs = self.engine.alloc_obs(FLAT_FIELDS)
+        self._terminal = {k: t.zeros_like(v) for k, v in self._obs.items()}
+        self._rows = t.zeros((n_envs, 5), dtype=t.int32, device=dev)
+        self._invalid = t.zeros(n_envs, dtype=t.uint8, device=dev)
+        self.timesteps = t.zeros(n_envs, dtype=t.int32, device=dev)
+        self.valid_action_count = t.zeros(n_envs, dtype=t.int64, device=dev)
+        self.invalid_action_count = t.zeros(n_envs, dtype=t.int64, device=dev)
+        self.episode_returns = t.zeros(n_envs, dtype=t.float64, device=dev)
+        self.reset()
+
+    # -- observation plumbing --
+    def _public(self, obs: Dict[str, object]) -> Dict[str, object]:
+        out = {"local_vulnerability": obs["mask_local"], "remote_vulnerability": obs["mask_remote"], "connect": obs["mask_connect"],
+               "leaked_credentials": obs["leaked_credentials"].reshape(self.num_envs, -1),
+               "credential_cache_matrix": obs["credential_cache_matrix"].reshape(self.num_envs, -1),
+               "discovered_nodes_properties": obs["discovered_nodes_properties"].reshape(self.num_envs, -1),
+               "nodes_privilegelevel": obs["nodes_privilegelevel"]}
+        for i, k in enumerate(SCALAR_KEYS):
+            out[k] = obs["scalars"][:, i]
+        return out
+
+    @property
+    def observation(self) -> Dict[str, object]:
+        return self._public(self._obs)
+
+    @property
+    def terminal_observation(self) -> Dict[str, object]:
+        return self._public(self._terminal)
+
+    def action_masks(self):
+        """[n_envs, N*N*P*C + N*L + N*N*R] bool, MaskedDiscreteAttackerWrapper order (connect, local, remote)."""
+        return self._obs["mask_discrete"] != 0
+
+    # -- VecEnv surface --
+    def reset(self):
+        self.engine.reset()
+        self.engine.observe(self._obs)
+        self.timesteps.zero_()
+        self.valid_action_count.zero_()
+        self.invalid_action_count.zero_()
+        self.episode_returns.zero_()
+        return self.observation
+
+    def step(self, actions):
+        """-> (observation dict, rewards f32 [E], terminated u8 [E], truncated u8 [E], info dict of tensors)."""
+        t = self.torch
+        if self.discrete:
+            self.engine.decode_attacker_actions(discrete=actions, actions_out=self._rows, invalid_out=self._invalid)
+        else:
+            self.engine.decode_attacker_actions(multidiscrete=actions, actions_out=self._rows, invalid_out=self._invalid)
+        reward, terminated = self.engine.step_observe(self._rows, self._obs)
+        invalid = self._invalid != 0
+        self.timesteps += 1
+        self.invalid_action_count += invalid
+        self.valid_action_count += ~invalid
+        rewards = reward + invalid.to(reward.dtype) * self.invalid_action_reward_modifier        # attack_wrapper.py:296,354
+        truncated = self.timesteps >= self.max_timesteps                                          # :350-352
+        terminated = terminated != 0
+        dones = terminated | truncated
+        self.episode_returns += rewards.double()
+        info = {"invalid_action": invalid, "cyber_step_executed": ~invalid,
+                "network_availability": self.engine.info["network_availability"], "step_count": self.engine.info["step_count"],
+                "episode_return": self.episode_returns.clone(), "episode_length": self.timesteps.clone()}
+        if self.auto_reset and bool(dones.any()):
+            for k in self._obs:
+                self._terminal[k].copy_(self._obs[k])
+            mask = dones.to(t.uint8)
+            self.engine.reset(mask)
+            self.engine.observe(self._obs, env_mask=mask)   # reset observation for the envs that ended; the others keep theirs
+            keep = ~dones
+            self.timesteps *= keep
+            self.valid_action_count *= keep
+            self.invalid_action_count *= keep
+            self.episode_returns *= keep
+        return self.observation, rewards, terminated.to(t.uint8), truncated.to(t.uint8), info
+
+    def close(self) -> None:
+        self.engine.close()

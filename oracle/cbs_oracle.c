@@ -440,6 +440,11 @@ typedef struct { double reward, raw; int terminated, truncated, oob, step_count;
  * RuntimeError("new episode must be started with env.reset()"). */
 static int step_env(const oracle* o, oenv* e, uint64_t env_gid, const int32_t a[5], const double* tape, int tape_len,
                     const oobs* obs, ostep* out) {
+    if (a[0] == MCBS_ACTION_SKIP && !(e->done || e->truncated)) {   /* env not stepped (attack_wrapper.py:292-308) */
+        out->reward = 0; out->raw = 0; out->terminated = 0; out->truncated = 0; out->oob = 0;
+        out->step_count = e->stepcount; out->availability = e->availability;
+        return 0;
+    }
     if (e->done || e->truncated) {
         out->reward = 0; out->raw = 0; out->terminated = e->done; out->truncated = e->truncated; out->oob = 0;
         out->step_count = e->stepcount; out->availability = e->availability;

@@ -1,0 +1,126 @@
+"""Golden traces of marlon's attacker wrappers, captured from the UNMODIFIED reference
+(marlon/baseline_models/env_wrappers/attack_wrapper.py, action_masking.py) over the reference CyberBattleEnv.
+Build container only:  python oracle/refharness/gen_golden_wrappers.py   ->  tests/golden/wrap_*.npz
+Data only: per step the wrapper-level action (MultiDiscrete(10) row or Discrete index), reward, terminated,
+truncated, invalid flag, every flat observation field, CRC32 of the Discrete action mask, defender draw tape.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import zlib
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import gen_golden as G  # noqa: E402  (loads the reference, installs the defender tape readers)
+
+ref = G.ref
+from marlon.baseline_models.env_wrappers.attack_wrapper import AttackerEnvWrapper  # noqa: E402
+from marlon.baseline_models.env_wrappers.action_masking import MaskedDiscreteAttackerWrapper  # noqa: E402
+
+FLAT = ["leaked_credentials", "credential_cache_matrix", "discovered_nodes_properties", "nodes_privilegelevel",
+        "local_vulnerability", "remote_vulnerability", "connect"]
+SCALARS = ["newly_discovered_nodes_count", "lateral_move", "customer_data_found", "probe_result", "escalation",
+           "credential_cache_length", "discovered_node_count"]
+
+
+def snap(obs):
+    out = {k: np.array(obs[k]) for k in FLAT}
+    out["scalars"] = np.array([int(obs[k]) for k in SCALARS], np.int32)
+    return out
+
+
+def run(name, make_cyber_env, spec, steps, seed, discrete, max_timesteps, tape_dps):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    cyber = make_cyber_env()
+    w = AttackerEnvWrapper(cyber, max_timesteps=max_timesteps, invalid_action_reward_modifier=-1)
+    m = MaskedDiscreteAttackerWrapper(w)
+    nvec = np.asarray(w.action_space.nvec)
+    obs, _ = m.reset(seed=seed)
+    rec = {k: [] for k in ["action", "reward", "terminated", "truncated", "invalid", "mask_crc", "mask_sum", "tape", "was_reset"] + FLAT + ["scalars"]}
+    rec_reset = {k: [] for k in FLAT + ["scalars"]}
+    first = snap(obs)
+    for t in range(steps):
+        mask = m.action_masks()
+        if discrete:
+            if rng.random() < 0.8:
+                a = int(rng.choice(np.flatnonzero(mask)))           # what MaskablePPO would sample from
+            else:
+                a = int(rng.integers(0, m.action_space.n))
+        else:
+            a = (rng.random(10) * nvec).astype(np.int64)
+            nd = int(obs["discovered_node_count"])
+            if rng.random() < 0.75:                                  # mostly in range, so that the env moves
+                for i in (1, 3, 4, 6, 7):
+                    a[i] = rng.integers(0, nd)
+                a[9] = rng.integers(0, max(1, int(obs["credential_cache_length"])))
+        tape = list(rng.random(tape_dps)) if tape_dps else []
+        if tape_dps:
+            G.TAPE.load(tape + [0.0] * 8)
+        obs, reward, terminated, truncated, info = (m.step(np.int64(a)) if discrete else w.step(a))
+        s = snap(obs)
+        rec["action"].append(a)
+        rec["reward"].append(float(reward))
+        rec["terminated"].append(int(terminated))
+        rec["truncated"].append(int(truncated))
+        rec["invalid"].append(int(bool(info.get("invalid_action", False))))
+        am = m.action_masks()
+        rec["mask_crc"].append(zlib.crc32(am.astype(np.int8).tobytes()))
+        rec["mask_sum"].append(int(am.sum()))
+        rec["tape"].append(tape)
+        for k in FLAT + ["scalars"]:
+            rec[k].append(s[k])
+        done = terminated or truncated
+        rec["was_reset"].append(int(done))
+        if done:
+            obs, _ = m.reset(seed=seed + 1000 * (t + 1))
+            r = snap(obs)
+            for k in FLAT + ["scalars"]:
+                rec_reset[k].append(r[k])
+    out = {k: np.asarray(v) for k, v in rec.items()}
+    out["tape"] = np.asarray(rec["tape"], np.float64).reshape(steps, -1)
+    out["mask_crc"] = out["mask_crc"].astype(np.uint32)
+    for k in FLAT + ["scalars"]:
+        out["first_" + k] = first[k]
+        if rec_reset[k]:
+            out["after_reset_" + k] = np.asarray(rec_reset[k])
+    spec = dict(spec, discrete=bool(discrete), max_timesteps=max_timesteps)
+    out["spec_json"] = np.frombuffer(json.dumps(spec).encode(), dtype=np.uint8)
+    path = os.path.join(G.GOLDEN, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name:28s} steps={steps} reward_sum={out['reward'].sum():8.1f} invalid={out['invalid'].sum():4d} "
+          f"dones={out['was_reset'].sum():3d} size={os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def main():
+    AG, DC, SAR = ref.env.AttackerGoal, ref.env.DefenderConstraint, ref.defender.ScanAndReimageCompromisedMachines
+
+    def goal(**kw):
+        g = dict(reward=0.0, low_availability=1.0, own_atleast=0, own_atleast_percent=1.0)
+        g.update(kw)
+        return g
+    sp_t = dict(maximum_node_count=12, maximum_total_credentials=10, maximum_discoverable_credentials_per_action=5,
+                attacker_goal=goal(own_atleast=6), winning_reward=5000.0, losing_reward=0.0, maintain_sla=0.80,
+                defender=["scan_and_reimage", 0.6, 2, 5])
+
+    def toyctf_def():
+        return ref.CyberBattleToyCtf(attacker_goal=AG(own_atleast=6), defender_agent=SAR(0.6, 2, 5),
+                                     defender_constraint=DC(maintain_sla=0.80), maximum_node_count=12,
+                                     maximum_total_credentials=10, throws_on_invalid_actions=False)
+    run("wrap_toyctf_md_s61", toyctf_def, sp_t, 260, 61, False, 120, 4)
+    run("wrap_toyctf_discrete_s62", toyctf_def, sp_t, 260, 62, True, 120, 4)
+    sp_c = dict(maximum_node_count=12, maximum_total_credentials=12, maximum_discoverable_credentials_per_action=5,
+                attacker_goal=goal(), winning_reward=5000.0, losing_reward=0.0, maintain_sla=0.0, defender=None)
+
+    def chain10():
+        return ref.CyberBattleChain(size=10, attacker_goal=AG(own_atleast_percent=1.0), maximum_node_count=12,
+                                    maximum_total_credentials=12, throws_on_invalid_actions=False)
+    run("wrap_chain10_md_s63", chain10, sp_c, 300, 63, False, 100, 0)
+    run("wrap_chain10_discrete_s64", chain10, sp_c, 300, 64, True, 100, 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -58,6 +58,14 @@ def load():
     from cyberbattle.samples.chainpattern import chainpattern
     from cyberbattle.samples.toyctf import toy_ctf
 
+    # marlon's wrappers import a plotly symbol that plotly 6 no longer ships (attack_wrapper.py:6); rendering only
+    if "plotly.missing_ipywidgets" not in sys.modules:
+        shim = types.ModuleType("plotly.missing_ipywidgets")
+        shim.FigureWidget = type("FigureWidget", (), {})
+        sys.modules["plotly.missing_ipywidgets"] = shim
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.append(REFERENCE_ROOT)          # `marlon.baseline_models.env_wrappers.*`
+
     ns = types.SimpleNamespace(env=env, defender=defender, actions=actions, model=model,
                                commandcontrol=commandcontrol, chainpattern=chainpattern, toy_ctf=toy_ctf,
                                CyberBattleChain=CyberBattleChain, CyberBattleToyCtf=CyberBattleToyCtf)

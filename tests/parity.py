@@ -39,7 +39,7 @@ def topology_for(trace_name: str) -> F.FlatTopology:
 
 
 def trace_names():
-    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
+    return sorted(n for n in (os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz"))) if not n.startswith("wrap_"))
 
 
 def load_trace(name: str):

@@ -1,0 +1,216 @@
+"""GPU tests of the host-side mirrors of the reference interface:
+the gym-shaped single-env facade and the batched counterparts of marlon's attacker wrappers, against golden traces
+captured from the reference's own classes."""
+import json
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from tests import parity
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = parity.GOLDEN
+
+
+def _env_for(name, sj, **kw):
+    from marlon_amd import cyberbattle_env as ce
+    from marlon_amd import model
+    from marlon_amd.samples import kitchen_sink
+    g = sj["attacker_goal"]
+    d = sj["defender"]
+    common = dict(maximum_node_count=sj["maximum_node_count"], maximum_total_credentials=sj["maximum_total_credentials"],
+                  maximum_discoverable_credentials_per_action=sj["maximum_discoverable_credentials_per_action"],
+                  attacker_goal=ce.AttackerGoal(**g), defender_constraint=ce.DefenderConstraint(maintain_sla=sj["maintain_sla"]),
+                  defender_agent=None if d is None else ce.ScanAndReimageCompromisedMachines(d[1], d[2], d[3]),
+                  winning_reward=sj["winning_reward"], losing_reward=sj["losing_reward"], throws_on_invalid_actions=False,
+                  draw_tape=d is not None)
+    common.update(kw)
+    if name.startswith("chain100"):
+        return ce.CyberBattleChain(size=100, **common)
+    if name.startswith("chain10"):
+        return ce.CyberBattleChain(size=10, **common)
+    if name.startswith("toyctf"):
+        return ce.CyberBattleToyCtf(**common)
+    if name.startswith("sink_evict"):
+        return ce.CyberBattleEnv(kitchen_sink.build(model, entry_reimagable=True), **common)
+    return ce.CyberBattleEnv(kitchen_sink.build(model), **common)
+
+
+VALID_TRACES = ["chain10_valid_s1", "chain10_valid_s2", "chain10_rewardgoal_s6", "toyctf_defender_s11", "toyctf_defender_s12",
+                "toyctf_slabreak_s16", "sink_evict_s44", "sink_attackerwin_s45", "chain100_defender_s31"]
+
+
+@pytest.mark.parametrize("name", VALID_TRACES)
+def test_gym_facade_reproduces_reference_episode_from_seeds(name):
+    """Same seeds as the harness -> sample_valid_action draws the reference's actions, step returns its results:
+    the whole loop `env.reset(seed); a = env.sample_valid_action(); env.step(a)` is interchangeable."""
+    z, sj = parity.load_trace(name)
+    seed = int(name.rsplit("_s", 1)[1])
+    env = _env_for(name, sj)
+    env.action_space.union_np_random = np.random.Generator(np.random.PCG64(seed + 1))
+    obs, info = env.reset(seed=seed)
+    np.testing.assert_array_equal(obs["discovered_nodes_properties"], z["reset_discovered_nodes_properties"])
+    np.testing.assert_array_equal(obs["action_mask"]["local_vulnerability"], z["reset_mask_local"])
+    assert info["network_availability"] == 1.0 and obs["credential_cache_length"] == 0
+    episode = 0
+    T = min(len(z["reward"]), 150 if name.startswith("chain100") else 400)
+    for t in range(T):
+        a = env.sample_valid_action()
+        row = [0, *a["local_vulnerability"], 0, 0] if "local_vulnerability" in a else \
+              [1, *a["remote_vulnerability"], 0] if "remote_vulnerability" in a else [2, *a["connect"]]
+        assert [int(x) for x in row] == z["actions"][t].tolist(), f"{name} step {t}: sampled action differs from the reference's"
+        if z["tape"].size:
+            env.set_draw_tape(z["tape"][t])
+        obs, reward, done, truncated, info = env.step(a)
+        assert reward == z["reward"][t] and done == bool(z["terminated"][t]) and truncated is False
+        assert info["step_count"] == z["step_count"][t]
+        assert np.float64(info["network_availability"]).view(np.uint64) == z["availability"][t].view(np.uint64)
+        assert [int(obs[k]) for k in ("newly_discovered_nodes_count", "lateral_move", "customer_data_found", "probe_result", "escalation",
+                                       "credential_cache_length", "discovered_node_count")] == z["scalars"][t].tolist()
+        np.testing.assert_array_equal(np.stack(obs["leaked_credentials"]), z["leaked_credentials"][t])
+        np.testing.assert_array_equal(obs["nodes_privilegelevel"], z["nodes_privilegelevel"][t])
+        assert [env.topo.node_ids.index(n) for n in obs["_discovered_nodes"]] == z["order"][t][:z["n_order"][t]].tolist()
+        if done:
+            with pytest.raises(RuntimeError, match=r"new episode must be started with env\.reset\(\)"):
+                env.step(a)
+            episode += 1
+            env.reset(seed=seed + 1000 * episode)
+    env.close()
+
+
+def test_gym_facade_errors_and_helpers():
+    from marlon_amd import cyberbattle_env as ce
+    with pytest.raises(ValueError, match=r"Network node count \(12\) exceeds the specified limit of 10"):
+        ce.CyberBattleChain(size=10, maximum_node_count=10, maximum_total_credentials=12)
+    env = ce.CyberBattleChain(size=10, maximum_node_count=12, maximum_total_credentials=12)      # throws_on_invalid_actions=True
+    obs, _ = env.reset(seed=0)
+    assert env.bounds.port_count == 8 and env.bounds.local_attacks_count == 5 and env.name == "CyberBattleChain-10"
+    assert env.is_node_owned(0) and env.compute_action_mask()["local_vulnerability"][0].tolist() == [0, 1, 0, 0, 0]
+    obs, r, done, _, _ = env.step({"local_vulnerability": np.array([0, 1])})
+    assert r == 14.0 and obs["discovered_node_count"] == 2 and not env.is_node_owned(1)
+    with pytest.raises(ValueError, match="Agent does not owned the node '1_LinuxNode'"):
+        env.step({"local_vulnerability": np.array([1, 0])})
+    with pytest.raises(ValueError, match="Agent does not owned the source node '1_LinuxNode'"):
+        env.step({"remote_vulnerability": np.array([1, 0, 0])})
+    assert env.is_action_valid({"connect": np.array([0, 1, 2, 0])}) and not env.is_action_valid({"connect": np.array([0, 1, 2, 1])})
+    obs, r, done, _, _ = env.step({"local_vulnerability": np.array([5, 0])})                     # out-of-bound: blank observation
+    assert r == 0.0 and (obs["discovered_nodes_properties"] == 2).all() and obs["action_mask"]["connect"].sum() == 0
+    assert env.compute_action_mask()["connect"].sum() > 0                                        # compute_action_mask is never blank
+    env.close()
+
+
+WRAP = ["wrap_toyctf_md_s61", "wrap_toyctf_discrete_s62", "wrap_chain10_md_s63", "wrap_chain10_discrete_s64"]
+FLAT = {"leaked_credentials": "leaked_credentials", "credential_cache_matrix": "credential_cache_matrix",
+        "discovered_nodes_properties": "discovered_nodes_properties", "nodes_privilegelevel": "nodes_privilegelevel",
+        "local_vulnerability": "local_vulnerability", "remote_vulnerability": "remote_vulnerability", "connect": "connect"}
+
+
+def _check_flat(obs, z, prefix, t, ctx):
+    from marlon_amd.cyberbattle_env import SCALAR_KEYS
+    ref = (lambda k: z[prefix + k]) if t is None else (lambda k: z[prefix + k][t])
+    assert [int(obs[k][0]) for k in SCALAR_KEYS] == ref("scalars").tolist(), ctx + " scalars"
+    for k in FLAT:
+        np.testing.assert_array_equal(obs[k][0].cpu().numpy().reshape(-1), np.asarray(ref(k)).reshape(-1), err_msg=f"{ctx} {k}")
+
+
+@pytest.mark.parametrize("name", WRAP)
+def test_attacker_vec_env_matches_marlon_wrappers(name):
+    """AttackerVecEnv (n_envs=1) == AttackerEnvWrapper / MaskedDiscreteAttackerWrapper of the reference, step by step:
+    decode, interception of undiscovered node indices, reward modifier, truncation, auto-reset, flat observation, mask."""
+    from marlon_amd import cyberbattle_env as ce
+    from marlon_amd._abi import RNG_TAPE
+    from marlon_amd.wrappers import AttackerVecEnv
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    sj = json.loads(bytes(z["spec_json"]).decode())
+    topo = parity.topology_for("toyctf" if "toyctf" in name else "chain10")
+    d = sj["defender"]
+    env = AttackerVecEnv(topo, 1, maximum_node_count=sj["maximum_node_count"], maximum_total_credentials=sj["maximum_total_credentials"],
+                         attacker_goal=ce.AttackerGoal(**sj["attacker_goal"]), defender_constraint=ce.DefenderConstraint(sj["maintain_sla"]),
+                         defender_agent=None if d is None else ce.ScanAndReimageCompromisedMachines(d[1], d[2], d[3]),
+                         max_timesteps=sj["max_timesteps"], discrete=sj["discrete"], rng_kind=RNG_TAPE)
+    _check_flat(env.observation, z, "first_", None, name + " reset")
+    resets = 0
+    for t in range(len(z["reward"])):
+        if z["tape"].size:
+            env.engine.set_draw_tape(z["tape"][t:t + 1])
+        a = np.asarray(z["action"][t]).reshape((1,) if sj["discrete"] else (1, 10))
+        obs, r, term, trunc, info = env.step(a)
+        ctx = f"{name} step {t}"
+        assert float(r[0]) == z["reward"][t], ctx + f" reward {float(r[0])} != {z['reward'][t]}"
+        assert int(term[0]) == z["terminated"][t] and int(trunc[0]) == z["truncated"][t], ctx + " flags"
+        assert int(info["invalid_action"][0]) == z["invalid"][t], ctx + " invalid"
+        if z["was_reset"][t]:
+            _check_flat(env.terminal_observation, z, "", t, ctx + " terminal")
+            _check_flat(obs, z, "after_reset_", resets, ctx + " after reset")
+            resets += 1
+        else:
+            _check_flat(obs, z, "", t, ctx)
+            m = env.action_masks()[0].cpu().numpy()
+            assert int(m.sum()) == z["mask_sum"][t] and zlib.crc32(m.astype(np.int8).tobytes()) == z["mask_crc"][t], ctx + " action mask"
+    env.close()
+
+
+def test_attacker_vec_env_batch_against_oracle():
+    """4 096 envs, MultiDiscrete actions drawn on the host, wrapper semantics reproduced with the oracle as checker."""
+    from marlon_amd import cyberbattle_env as ce
+    from marlon_amd.wrappers import AttackerVecEnv
+    from oracle.oracle import Oracle
+    topo = parity.topology_for("toyctf")
+    E, T = 4096, 80
+    env = AttackerVecEnv(topo, E, maximum_node_count=12, maximum_total_credentials=10, attacker_goal=ce.AttackerGoal(own_atleast=6),
+                         defender_agent=ce.ScanAndReimageCompromisedMachines(0.6, 2, 5), defender_constraint=ce.DefenderConstraint(0.8),
+                         max_timesteps=50, seed=11)
+    orc = Oracle(topo, env.spec)
+    rng = np.random.Generator(np.random.PCG64(3))
+    timesteps = np.zeros(E, np.int64)
+    n_disc = np.ones(E, np.int64)
+    for t in range(T):
+        a = (rng.random((E, 10)) * env.nvec).astype(np.int64)
+        fix = rng.random(E) < 0.7
+        for i in (1, 3, 4, 6, 7):
+            a[fix, i] = (rng.random(fix.sum()) * n_disc[fix]).astype(np.int64)
+        kind = a[:, 0]
+        src = np.where(kind == 0, a[:, 1], np.where(kind == 1, a[:, 3], a[:, 6]))
+        tgt = np.where(kind == 0, 0, np.where(kind == 1, a[:, 4], a[:, 7]))
+        valid = (src < n_disc) & ((kind == 0) | (tgt < n_disc))
+        rows = np.zeros((E, 5), np.int32)
+        rows[:, 0] = np.where(valid, kind, 3)
+        rows[:, 1] = src
+        rows[:, 2] = np.where(kind == 0, a[:, 2], tgt)
+        rows[:, 3] = np.where(kind == 1, a[:, 5], np.where(kind == 2, a[:, 8], 0))
+        rows[:, 4] = np.where(kind == 2, a[:, 9], 0)
+        obs, r, term, trunc, info = env.step(a)
+        o = orc.step(rows)
+        timesteps += 1
+        exp_r = o["reward"] + np.where(valid, 0.0, -1.0)
+        np.testing.assert_array_equal(r.double().cpu().numpy(), exp_r, err_msg=f"step {t} reward")
+        np.testing.assert_array_equal(term.cpu().numpy(), o["terminated"], err_msg=f"step {t} terminated")
+        np.testing.assert_array_equal(trunc.cpu().numpy(), (timesteps >= 50).astype(np.uint8), err_msg=f"step {t} truncated")
+        np.testing.assert_array_equal(info["invalid_action"].cpu().numpy(), ~valid)
+        dones = (o["terminated"] != 0) | (timesteps >= 50)
+        for i in np.flatnonzero(dones):
+            orc.reset(int(i))
+        timesteps[dones] = 0
+        n_disc = obs["discovered_node_count"].cpu().numpy().astype(np.int64)
+        _, _, order, _ = orc.get_state()
+        np.testing.assert_array_equal(n_disc, (order != 0xFFFF).sum(axis=1), err_msg=f"step {t} discovered count after reset")
+    env.close()
+
+
+def test_run_episodes_random_policy_finishes_chain4():
+    """Episode driver (marlon.simulate counterpart): masked-random attackers own the whole Chain-4 network."""
+    from marlon_amd import cyberbattle_env as ce
+    from marlon_amd.samples import chainpattern
+    from marlon_amd.simulate import random_policy, run_episodes
+    from marlon_amd.wrappers import AttackerVecEnv
+    env = AttackerVecEnv(chainpattern.new_environment(4), 512, maximum_node_count=6, maximum_total_credentials=6,
+                         attacker_goal=ce.AttackerGoal(own_atleast_percent=1.0), max_timesteps=400, discrete=True)
+    out = run_episodes(env, random_policy(seed=3), max_steps=400)
+    ep = out["episodes"].cpu().numpy()
+    assert (ep >= 1).all()                                        # every env ended at least one episode (win or truncation)
+    r = out["rewards"].cpu().numpy()
+    assert (r == 5000.0).sum() > 0 and r.min() >= 0.0             # some wins; masked actions are never intercepted (no -1 modifier)
+    env.close()
