@@ -194,10 +194,12 @@ extern "C" int mcbs_batch_create(const mcbs_topology* topo, const mcbs_batch_cfg
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     const size_t o_h0 = take(16ull * E), o_h1 = take(16ull * E), o_ep = take(4ull * E), o_pend = take(8ull * E);
-    size_t o_mask[M_COUNT];
-    for (int k = 0; k < M_COUNT; ++k) o_mask[k] = take(8ull * (k == M_GATH ? S.SW : (k == M_CACH ? S.TW : S.NW)) * E);
+    uint32_t wt = S.NW > S.SW ? S.NW : S.SW;
+    if (S.TW > wt) wt = S.TW;
+    S.WT = wt <= 1 ? 1 : (wt == 2 ? 2 : 4);
+    const size_t o_masks = take(8ull * M_COUNT * S.WT * E);
     const bool has_def = cfg->defender_kind != MCBS_DEFENDER_NONE;
-    const size_t o_ring = has_def ? take(8ull * 16 * S.NW * E) : 0;
+    const size_t o_ring = has_def ? take(8ull * 16 * S.WT * E) : 0;
     const size_t o_init = take(S.body_stride);
     const size_t o_digest = take(sizeof(ObsDigest) * (size_t)E);
     const size_t o_body = take((size_t)S.body_stride * E);
@@ -209,7 +211,7 @@ extern "C" int mcbs_batch_create(const mcbs_topology* topo, const mcbs_batch_cfg
     uint8_t* a = b->arena;
     S.h0 = reinterpret_cast<uint4*>(a + o_h0); S.h1 = reinterpret_cast<double2*>(a + o_h1);
     S.episode = reinterpret_cast<uint32_t*>(a + o_ep); S.pending = reinterpret_cast<double*>(a + o_pend);
-    for (int k = 0; k < M_COUNT; ++k) S.mask[k] = reinterpret_cast<uint64_t*>(a + o_mask[k]);
+    S.masks = reinterpret_cast<uint64_t*>(a + o_masks);
     S.ring = has_def ? reinterpret_cast<uint64_t*>(a + o_ring) : nullptr;
     S.body = a + o_body; S.init_body = a + o_init;
     b->digest = reinterpret_cast<ObsDigest*>(a + o_digest);
@@ -311,25 +313,29 @@ static int timing_end(mcbs_batch* b, hipStream_t st, size_t slot) {
     return MCBS_OK;
 }
 
-// Kernel variant: node-mask words kept in registers (1, 2 or 4) and whether the topology tables fit the LDS budget.
-template <int PHASE, int NWT>
-static void launch_step_nw(mcbs_batch* b, const StepIO& io, hipStream_t st) {
+// Kernel variant: words per set kept in registers (1, 2 or 4), whether the topology tables fit the LDS budget, and
+// whether an in-env defender is configured (its code and loads are compiled out otherwise).
+template <int PHASE, int WT, bool DEF>
+static void launch_step_v(mcbs_batch* b, const StepIO& io, hipStream_t st) {
     const uint32_t E = b->S.E, lds = b->C.lds_bytes;
     if (lds <= 60000u && !getenv("MCBS_NO_LDS_TOPO")) {
         const uint32_t block = lds <= 8192u ? 64u : 256u;
-        hipLaunchKernelGGL((step_kernel<PHASE, NWT, true>), dim3((E + block - 1) / block), dim3(block), lds, st, b->S, b->T, b->C, io);
+        hipLaunchKernelGGL((step_kernel<PHASE, WT, true, DEF>), dim3((E + block - 1) / block), dim3(block), lds, st, b->S, b->T, b->C, io);
     } else {
-        hipLaunchKernelGGL((step_kernel<PHASE, NWT, false>), dim3((E + 127) / 128), dim3(128), 0, st, b->S, b->T, b->C, io);
+        hipLaunchKernelGGL((step_kernel<PHASE, WT, false, DEF>), dim3((E + 127) / 128), dim3(128), 0, st, b->S, b->T, b->C, io);
     }
+}
+
+template <int PHASE, int WT>
+static void launch_step_nw(mcbs_batch* b, const StepIO& io, hipStream_t st) {
+    if (b->cfg.defender_kind != MCBS_DEFENDER_NONE) launch_step_v<PHASE, WT, true>(b, io, st);
+    else launch_step_v<PHASE, WT, false>(b, io, st);
 }
 
 template <int PHASE>
 static int launch_step(mcbs_batch* b, const StepIO& io, hipStream_t st, const char* what) {
-    uint32_t wt = b->S.NW;
-    if (b->S.SW > wt) wt = b->S.SW;
-    if (b->S.TW > wt) wt = b->S.TW;
-    if (wt <= 1) launch_step_nw<PHASE, 1>(b, io, st);
-    else if (wt == 2) launch_step_nw<PHASE, 2>(b, io, st);
+    if (b->S.WT == 1) launch_step_nw<PHASE, 1>(b, io, st);
+    else if (b->S.WT == 2) launch_step_nw<PHASE, 2>(b, io, st);
     else launch_step_nw<PHASE, 4>(b, io, st);
     return launch_ok(what);
 }
@@ -466,7 +472,7 @@ extern "C" int mcbs_get_state(mcbs_batch* b, void* host_buf, size_t nbytes) {
     const double2* h1 = reinterpret_cast<const double2*>(at(S.h1));
     const uint32_t* ep = reinterpret_cast<const uint32_t*>(at(S.episode));
     const uint64_t* mk[M_COUNT];
-    for (int k = 0; k < M_COUNT; ++k) mk[k] = reinterpret_cast<const uint64_t*>(at(S.mask[k]));
+    for (int k = 0; k < M_COUNT; ++k) mk[k] = reinterpret_cast<const uint64_t*>(at(S.mask(k)));
     const uint64_t* ring = S.ring ? reinterpret_cast<const uint64_t*>(at(S.ring)) : nullptr;
     const uint8_t* body = at(S.body);
     memset(host_buf, 0, rb * S.E);
@@ -496,7 +502,7 @@ extern "C" int mcbs_get_state(mcbs_batch* b, void* host_buf, size_t nbytes) {
             if (!sn[n].running && ring) {   // remaining steps = distance from the defender clock to the node's ring slot
                 const uint32_t d = (h0[e].w >> 16) & 15u;
                 for (uint32_t s = 0; s < 16u; ++s)
-                    if (ring[((size_t)s * S.NW + (n >> 6)) * S.E + e] & bit) sn[n].countdown = (uint8_t)((s + 16u - d) & 15u);
+                    if (ring[((size_t)s * S.WT + (n >> 6)) * S.E + e] & bit) sn[n].countdown = (uint8_t)((s + 16u - d) & 15u);
             }
         }
         uint16_t* order = reinterpret_cast<uint16_t*>(p + sizeof(mcbs_state_header) + sizeof(mcbs_state_node) * S.N);

@@ -45,12 +45,13 @@ struct DevState {
     double2*  h1;       // [E] {cum_reward, availability}
     uint32_t* episode;  // [E]
     double*   pending;  // [E] raw reward carried between the split phases of mcbs_step_observe
-    uint64_t* mask[M_COUNT]; // discovered / agent installed / ever owned / running / privilege bit 0 / bit 1 : [NW][E]
-                             // gathered credential strings [SW][E], cached credential triples [TW][E]
+    uint64_t* masks;    // [M_COUNT][WT][E]: discovered / agent installed / ever owned / running / privilege bit 0 / bit 1 /
+                        // gathered credential strings / cached credential triples; every set padded to WT words
+    __host__ __device__ __forceinline__ uint64_t* mask(int k) const { return masks + (size_t)k * WT * E; }
     uint64_t* ring;     // [16][NW][E] nodes being re-imaged, by the defender tick (mod 16) that releases them; null without defender
     uint8_t*  body;     // [E][body_stride]
     const uint8_t* init_body; // [body_stride] image of a freshly reset env
-    uint32_t E, N, NW, SW, TW;
+    uint32_t E, N, NW, SW, TW, WT;  // WT = words per set = max(NW, SW, TW) rounded to 1, 2 or 4
     uint32_t body_stride, off_disc, off_cred, off_rows, Cmax;
 };
 
@@ -132,12 +133,13 @@ __device__ __forceinline__ void reset_header(const DevState& S, const Topo& T, u
         }
         const uint32_t rem = S.N - w * 64u;
         const size_t k = (size_t)w * S.E + e;
-        S.mask[M_DISC][k] = m; S.mask[M_INST][k] = m; S.mask[M_EVER][k] = m; S.mask[M_PLO][k] = lo; S.mask[M_PHI][k] = hi;
-        S.mask[M_RUN][k] = rem >= 64u ? ~0ull : ((1ull << rem) - 1ull);
-        if (S.ring) for (uint32_t s = 0; s < 16u; ++s) S.ring[((size_t)s * S.NW + w) * S.E + e] = 0;
+        S.mask(M_DISC)[k] = m; S.mask(M_INST)[k] = m; S.mask(M_EVER)[k] = m; S.mask(M_PLO)[k] = lo; S.mask(M_PHI)[k] = hi;
+        S.mask(M_RUN)[k] = rem >= 64u ? ~0ull : ((1ull << rem) - 1ull);
+        if (S.ring) for (uint32_t s = 0; s < 16u; ++s) S.ring[((size_t)s * S.WT + w) * S.E + e] = 0;
     }
-    for (uint32_t w = 0; w < S.SW; ++w) S.mask[M_GATH][(size_t)w * S.E + e] = 0;
-    for (uint32_t w = 0; w < S.TW; ++w) S.mask[M_CACH][(size_t)w * S.E + e] = 0;
+    for (uint32_t w = 0; w < S.WT; ++w) { S.mask(M_GATH)[(size_t)w * S.E + e] = 0; S.mask(M_CACH)[(size_t)w * S.E + e] = 0; }
+    for (uint32_t w = S.NW; w < S.WT; ++w)
+        for (int k = 0; k < M_GATH; ++k) S.mask(k)[(size_t)w * S.E + e] = 0;
     S.h0[e] = make_uint4(0u, 0u, n_init, n_init);
     S.h1[e] = make_double2(0.0, 1.0);
     S.episode[e] = episode;

@@ -214,6 +214,7 @@ struct Lane {
     }
 
     __device__ __forceinline__ uint64_t valid_bits(uint32_t w) const {
+        if (w * 64u >= S.N) return 0ull;
         const uint32_t rem = S.N - w * 64u;
         return rem >= 64u ? ~0ull : ((1ull << rem) - 1ull);
     }
@@ -225,7 +226,7 @@ struct Lane {
 #pragma unroll
         for (int w = 0; w < WT; ++w) {
             if (back[w]) { m[M_RUN][w] |= back[w]; dirty |= 1u << M_RUN; }
-            if ((uint32_t)w < S.NW) imaging += __popcll(~m[M_RUN][w] & valid_bits(w));
+            imaging += __popcll(~m[M_RUN][w] & valid_bits(w));
         }
         if (!imaging) return C.full_availability;
         double s;
@@ -233,7 +234,6 @@ struct Lane {
             s = C.full_sum;
 #pragma unroll
             for (int w = 0; w < WT; ++w) {
-                if ((uint32_t)w >= S.NW) break;
                 uint64_t im = ~m[M_RUN][w] & valid_bits(w);
                 while (im) { const uint32_t b = (uint32_t)__builtin_ctzll(im); im &= im - 1; s -= NS(w * 64u + b)->avail_term; }
             }
@@ -269,7 +269,7 @@ struct Lane {
 // PHASE 0: whole step.  PHASE 1: attacker's action only (raw reward parked in S.pending).
 // PHASE 2: defender, goals, outputs, auto-reset (after the observation kernels ran).
 // WT: words per set held in registers (1, 2 or 4; >= NW, SW, TW).  TOPO_LDS: topology tables staged in LDS.
-template <int PHASE, int WT, bool TOPO_LDS>
+template <int PHASE, int WT, bool TOPO_LDS, bool DEF>
 __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, StepCfg C, StepIO io) {
     extern __shared__ uint4 topo_lds[];
 #ifdef MCBS_DIAG
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, StepCfg C
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = e < S.E;
     const uint32_t ec = active ? e : 0u;                // clamp so inactive lanes read valid memory and take no branch
-    const bool has_def = C.defender_kind != MCBS_DEFENDER_NONE;
+    constexpr bool has_def = DEF;   // C.defender_kind != MCBS_DEFENDER_NONE, resolved at launch
 
     // ---------------- level 1: loads whose addresses depend on the env index only ----------------
     uint8_t* body = S.body + (size_t)ec * S.body_stride;
@@ -300,13 +300,12 @@ __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, StepCfg C
         chead0 = *reinterpret_cast<const uint4*>(body + S.off_cred);
         chead1 = *reinterpret_cast<const uint4*>(body + S.off_cred + 16);
     }
-    uint64_t m0[M_COUNT][WT];
+    uint64_t m0[M_COUNT][WT];        // every set is stored padded to WT words: no bounds to test, all loads independent
 #pragma unroll
     for (int k = 0; k < M_COUNT; ++k) {
-        const uint32_t words = k == M_GATH ? S.SW : (k == M_CACH ? S.TW : S.NW);
         const bool wanted = PHASE != 2 || (k != M_GATH && k != M_CACH && k != M_DISC && k != M_EVER);
 #pragma unroll
-        for (int w = 0; w < WT; ++w) m0[k][w] = (wanted && (uint32_t)w < words) ? S.mask[k][(uint32_t)w * S.E + ec] : 0ull;
+        for (int w = 0; w < WT; ++w) m0[k][w] = wanted ? S.masks[((uint32_t)k * WT + (uint32_t)w) * S.E + ec] : 0ull;
     }
     double2 h1 = make_double2(0.0, 0.0);
     uint32_t episode = 0;
@@ -356,7 +355,7 @@ __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, StepCfg C
         uint64_t back[WT];
 #pragma unroll
         for (int w = 0; w < WT; ++w)
-            back[w] = (PHASE != 1 && has_def && (uint32_t)w < S.NW) ? S.ring[((ln.dclk & 15u) * S.NW + (uint32_t)w) * S.E + e] : 0ull;
+            back[w] = (PHASE != 1 && has_def) ? S.ring[((ln.dclk & 15u) * WT + (uint32_t)w) * S.E + e] : 0ull;
 
         bool oob = false;
         if (PHASE != 2) {
@@ -424,7 +423,7 @@ __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, StepCfg C
                     ln.defender_scan(step, episode, io, fresh);
 #pragma unroll
                     for (int w = 0; w < WT; ++w)       // the slot now holds the nodes re-imaged at this tick (released 16 ticks on)
-                        if ((uint32_t)w < S.NW && fresh[w] != back[w]) S.ring[((ln.dclk & 15u) * S.NW + (uint32_t)w) * S.E + e] = fresh[w];
+                        if (fresh[w] != back[w]) S.ring[((ln.dclk & 15u) * WT + (uint32_t)w) * S.E + e] = fresh[w];
                     ln.dclk = (ln.dclk + 1u) & 0xFFFFu;
                 }
                 // goals (env.py:1080-1116) on the state AFTER the defender acted, availability from BEFORE its scan
@@ -461,10 +460,9 @@ __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, StepCfg C
 #pragma unroll
             for (int k = 0; k < M_COUNT; ++k) {
                 if (!((ln.dirty >> k) & 1u)) continue;
-                const uint32_t words = k == M_GATH ? S.SW : (k == M_CACH ? S.TW : S.NW);
 #pragma unroll
                 for (int w = 0; w < WT; ++w)
-                    if ((uint32_t)w < words && ln.m[k][w] != m0[k][w]) S.mask[k][(uint32_t)w * S.E + e] = ln.m[k][w];
+                    if (WT == 1 || ln.m[k][w] != m0[k][w]) S.masks[((uint32_t)k * WT + (uint32_t)w) * S.E + e] = ln.m[k][w];
             }
         }
     }
