@@ -39,11 +39,11 @@ extern "C" {
 /* ---- engine limits ---- */
 #define MCBS_MAX_NODES        256   /* node ids are u8; masks are <= 4 x u64 */
 #define MCBS_MAX_PORTS         32   /* firewall / listen tables are u32 port masks */
-#define MCBS_MAX_PROPS         64   /* property sets are u64 masks */
+#define MCBS_MAX_PROPS         60   /* property sets share a u64 with the 4 privilege tags of a node row */
 #define MCBS_MAX_SLOTS         32   /* vulnerabilities applicable to one node (library + own) */
 #define MCBS_MAX_LOCAL_VULNS   32   /* local-vulnerability mask per node is u32 */
-#define MCBS_MAX_CRED_STRINGS 1024
-#define MCBS_MAX_TRIPLES      4096  /* distinct (node, port, credential) triples */
+#define MCBS_MAX_CRED_STRINGS 256    /* every set is held in <= 4 x u64 registers per env */
+#define MCBS_MAX_TRIPLES      256   /* distinct (node, port, credential) triples */
 
 /* ================================================================================
  * Topology blob ("MCBT", little endian, every section 16-byte aligned).

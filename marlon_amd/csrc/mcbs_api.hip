@@ -33,9 +33,14 @@ static int fail(int code, const char* fmt, ...) {
         if (_e != hipSuccess) return fail(MCBS_EHIP, "%s failed: %s", #expr, hipGetErrorString(_e));      \
     } while (0)
 
+struct HotLayout { uint32_t node, desc, payload, service, allowed, triple, avail, bytes; };
+
 struct mcbs_topology {
     std::vector<uint8_t> host;
+    std::vector<uint8_t> hot_host;  // step kernel's view of the tables (mcbs_device.h "hot image")
+    HotLayout hot{};
     uint8_t* dev = nullptr;
+    uint8_t* hot_dev = nullptr;
     int32_t device = 0;
     const mcbs_topo_header* H() const { return reinterpret_cast<const mcbs_topo_header*>(host.data()); }
 };
@@ -46,6 +51,7 @@ struct mcbs_batch {
     DevState S{};
     Topo T{};
     StepCfg C{};
+    StepCfg* C_dev = nullptr;       // device copy read by the step kernel through the scalar cache
     uint8_t* arena = nullptr;       // every per-env column + bodies + init body, one allocation
     size_t arena_bytes = 0;
     ObsDigest* digest = nullptr;
@@ -77,7 +83,7 @@ extern "C" int mcbs_topology_create(const void* blob, size_t nbytes, int32_t dev
     if (h->abi_version != MCBS_ABI_VERSION) return fail(MCBS_EINVAL, "topology blob: ABI version %u, library %u", h->abi_version, MCBS_ABI_VERSION);
     if (h->total_bytes != nbytes || h->header_bytes != sizeof(mcbs_topo_header)) return fail(MCBS_EINVAL, "topology blob: size mismatch");
     if (h->n_nodes == 0 || h->n_nodes > MCBS_MAX_NODES) return fail(MCBS_ELIMIT, "n_nodes %u outside 1..%d", h->n_nodes, MCBS_MAX_NODES);
-    if (h->n_ports == 0 || h->n_ports > MCBS_MAX_PORTS || h->n_props > MCBS_MAX_PROPS || h->max_slots == 0 || h->max_slots > MCBS_MAX_SLOTS ||
+    if (h->n_ports == 0 || h->n_ports > MCBS_MAX_PORTS || h->n_props > 60u || h->max_slots == 0 || h->max_slots > MCBS_MAX_SLOTS ||
         h->n_local == 0 || h->n_local > MCBS_MAX_LOCAL_VULNS || h->n_remote == 0 || h->n_cred_strings > MCBS_MAX_CRED_STRINGS ||
         h->n_triples > MCBS_MAX_TRIPLES)
         return fail(MCBS_ELIMIT, "topology exceeds an engine limit");
@@ -130,11 +136,52 @@ extern "C" int mcbs_topology_create(const void* blob, size_t nbytes, int32_t dev
     if (!t) return fail(MCBS_ENOMEM, "out of memory");
     t->host.assign(b, b + nbytes);
     t->device = device;
+    {   // hot image: 32-byte node records, flattened (node, column) descriptors, then the list sections verbatim
+        const uint32_t N = h->n_nodes, W = h->n_local + h->n_remote;
+        HotLayout& L = t->hot;
+        uint32_t off = 0;
+        auto take = [&](size_t bytes) { uint32_t o = off; off = (uint32_t)((off + bytes + 15) / 16 * 16); return o; };
+        L.node = take(sizeof(HotNode) * N);
+        L.desc = take(sizeof(HotDesc) * (size_t)N * W);
+        L.payload = take(sizeof(mcbs_payload) * h->n_payload);
+        L.service = take(sizeof(mcbs_service) * h->n_services);
+        L.allowed = take(sizeof(uint16_t) * h->n_allowed);
+        L.triple = take(sizeof(mcbs_triple) * h->n_triples);
+        L.avail = take(sizeof(double) * N);
+        L.bytes = off;
+        t->hot_host.assign(off, 0);
+        uint8_t* hb = t->hot_host.data();
+        for (uint32_t n = 0; n < N; ++n) {
+            HotNode hn{};
+            hn.props = ns[n].props; hn.value = ns[n].value; hn.fw_in_allow = ns[n].fw_in_allow; hn.fw_out_allow = ns[n].fw_out_allow;
+            hn.listen = ns[n].listen; hn.svc_off = ns[n].svc_off; hn.svc_cnt = ns[n].svc_cnt; hn.flags = ns[n].flags;
+            memcpy(hb + L.node + sizeof(HotNode) * n, &hn, sizeof(hn));
+            memcpy(hb + L.avail + sizeof(double) * n, &ns[n].avail_term, sizeof(double));
+            for (uint32_t c = 0; c < W; ++c) {
+                HotDesc d{};
+                const uint8_t s = so[(size_t)n * W + c];
+                d.kind = 0xFF;
+                if (s != 0xFF) {
+                    const mcbs_vuln_slot& v = sl[(size_t)n * h->max_slots + s];
+                    d.cost = v.cost; d.probe_mask = v.probe_mask; d.payload_off = v.payload_off; d.payload_cnt = v.payload_cnt;
+                    d.precond_tt = v.precond_tt; d.kind = v.kind; d.level = v.level; d.slot = s;
+                }
+                memcpy(hb + L.desc + sizeof(HotDesc) * ((size_t)n * W + c), &d, sizeof(d));
+            }
+        }
+        memcpy(hb + L.payload, pl, sizeof(mcbs_payload) * h->n_payload);
+        memcpy(hb + L.service, sv, sizeof(mcbs_service) * h->n_services);
+        memcpy(hb + L.allowed, b + h->off_allowed, sizeof(uint16_t) * h->n_allowed);
+        memcpy(hb + L.triple, tr, sizeof(mcbs_triple) * h->n_triples);
+    }
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipMalloc(&t->dev, nbytes);
     if (e == hipSuccess) e = hipMemcpy(t->dev, blob, nbytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&t->hot_dev, t->hot_host.size());
+    if (e == hipSuccess) e = hipMemcpy(t->hot_dev, t->hot_host.data(), t->hot_host.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         if (t->dev) (void)hipFree(t->dev);
+        if (t->hot_dev) (void)hipFree(t->hot_dev);
         delete t;
         return fail(MCBS_EHIP, "topology upload failed: %s", hipGetErrorString(e));
     }
@@ -145,6 +192,7 @@ extern "C" int mcbs_topology_create(const void* blob, size_t nbytes, int32_t dev
 extern "C" void mcbs_topology_destroy(mcbs_topology* t) {
     if (!t) return;
     if (t->dev) { (void)hipSetDevice(t->device); (void)hipFree(t->dev); }
+    if (t->hot_dev) (void)hipFree(t->hot_dev);
     delete t;
 }
 
@@ -188,8 +236,8 @@ extern "C" int mcbs_batch_create(const mcbs_topology* topo, const mcbs_batch_cfg
     S.Cmax = cfg->maximum_total_credentials;
     S.off_disc = 0;                                                             // u8 discovery order, >= 16 bytes
     S.off_cred = (uint32_t)align_up((size_t)N, 16);                             // u16 credential cache, >= 32 bytes
-    S.off_rows = (uint32_t)align_up((size_t)S.off_cred + (2u * h->n_triples > 32u ? 2u * h->n_triples : 32u), 32);
-    S.body_stride = (uint32_t)align_up((size_t)S.off_rows + 32u * N, 64);
+    S.off_rows = (uint32_t)align_up((size_t)S.off_cred + (2u * h->n_triples > 32u ? 2u * h->n_triples : 32u), 16);
+    S.body_stride = (uint32_t)align_up((size_t)S.off_rows + sizeof(Row) * N, 64);
 
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
@@ -216,6 +264,7 @@ extern "C" int mcbs_batch_create(const mcbs_topology* topo, const mcbs_batch_cfg
     S.body = a + o_body; S.init_body = a + o_init;
     b->digest = reinterpret_cast<ObsDigest*>(a + o_digest);
     b->T.base = topo->dev;
+    b->T.hot = topo->hot_dev;
 
     // reset image of one env body: rows of the initially owned nodes know all their properties and carry
     // max(initial privilege, LocalUser) (actions.py:149-152,263-270); every row carries its literal tags
@@ -224,9 +273,8 @@ extern "C" int mcbs_batch_create(const mcbs_topology* topo, const mcbs_batch_cfg
     for (uint32_t n = 0; n < N; ++n) {
         Row r{};
         const bool owned0 = (ns[n].flags & MCBS_NODE_INSTALLED0) != 0;
-        r.props = owned0 ? ns[n].props : 0;
-        r.tags = ns[n].tags0;
-        memcpy(init.data() + S.off_rows + 32u * n, &r, sizeof(r));
+        r.props_tags = (owned0 ? ns[n].props : 0ull) | ((uint64_t)(ns[n].tags0 & 0xFu) << 60);
+        memcpy(init.data() + S.off_rows + sizeof(Row) * n, &r, sizeof(r));
     }
     memcpy(init.data() + S.off_disc, topo->host.data() + h->off_init_order, h->n_init_owned);
     e = hipMemcpy(a + o_init, init.data(), init.size(), hipMemcpyHostToDevice);
@@ -247,8 +295,12 @@ extern "C" int mcbs_batch_create(const mcbs_topology* topo, const mcbs_batch_cfg
     C.K = cfg->maximum_discoverable_credentials_per_action;
     C.off_node = h->off_node; C.off_slot_of = h->off_slot_of; C.off_slot = h->off_slot; C.off_payload = h->off_payload;
     C.off_service = h->off_service; C.off_allowed = h->off_allowed; C.off_triple = h->off_triple;
-    C.lds_bytes = h->off_code;
+    C.hot_node = topo->hot.node; C.hot_desc = topo->hot.desc; C.hot_payload = topo->hot.payload; C.hot_service = topo->hot.service;
+    C.hot_allowed = topo->hot.allowed; C.hot_triple = topo->hot.triple; C.hot_avail = topo->hot.avail; C.hot_bytes = topo->hot.bytes;
 
+    e = hipMalloc(&b->C_dev, sizeof(StepCfg));
+    if (e == hipSuccess) e = hipMemcpy(b->C_dev, &b->C, sizeof(StepCfg), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(b->arena); delete b; return fail(MCBS_EHIP, "config upload failed: %s", hipGetErrorString(e)); }
     hipLaunchKernelGGL(reset_kernel, dim3((E + 127) / 128), dim3(128), 0, 0, S, b->T, (const uint8_t*)nullptr, 0);
     e = hipDeviceSynchronize();
     if (e != hipSuccess) { (void)hipFree(b->arena); delete b; return fail(MCBS_EHIP, "initial reset failed: %s", hipGetErrorString(e)); }
@@ -261,6 +313,7 @@ extern "C" void mcbs_batch_destroy(mcbs_batch* b) {
     (void)hipSetDevice(b->cfg.device);
     for (hipEvent_t ev : b->ev) (void)hipEventDestroy(ev);
     if (b->arena) (void)hipFree(b->arena);
+    if (b->C_dev) (void)hipFree(b->C_dev);
     delete b;
 }
 
@@ -317,12 +370,12 @@ static int timing_end(mcbs_batch* b, hipStream_t st, size_t slot) {
 // whether an in-env defender is configured (its code and loads are compiled out otherwise).
 template <int PHASE, int WT, bool DEF>
 static void launch_step_v(mcbs_batch* b, const StepIO& io, hipStream_t st) {
-    const uint32_t E = b->S.E, lds = b->C.lds_bytes;
+    const uint32_t E = b->S.E, lds = b->C.hot_bytes;
     if (lds <= 60000u && !getenv("MCBS_NO_LDS_TOPO")) {
         const uint32_t block = lds <= 8192u ? 64u : 256u;
-        hipLaunchKernelGGL((step_kernel<PHASE, WT, true, DEF>), dim3((E + block - 1) / block), dim3(block), lds, st, b->S, b->T, b->C, io);
+        hipLaunchKernelGGL((step_kernel<PHASE, WT, true, DEF>), dim3((E + block - 1) / block), dim3(block), lds, st, b->S, b->T, b->C_dev, io);
     } else {
-        hipLaunchKernelGGL((step_kernel<PHASE, WT, false, DEF>), dim3((E + 127) / 128), dim3(128), 0, st, b->S, b->T, b->C, io);
+        hipLaunchKernelGGL((step_kernel<PHASE, WT, false, DEF>), dim3((E + 127) / 128), dim3(128), 0, st, b->S, b->T, b->C_dev, io);
     }
 }
 
@@ -490,14 +543,14 @@ extern "C" int mcbs_get_state(mcbs_batch* b, void* host_buf, size_t nbytes) {
         const uint8_t* eb = body + (size_t)e * S.body_stride;
         for (uint32_t n = 0; n < S.N; ++n) {
             Row r;
-            memcpy(&r, eb + S.off_rows + 32u * n, sizeof(r));
+            memcpy(&r, eb + S.off_rows + sizeof(Row) * n, sizeof(r));
             const size_t k = (size_t)(n >> 6) * S.E + e;
             const uint64_t bit = 1ull << (n & 63u);
-            sn[n].discovered_props = r.props; sn[n].attacked_ever = r.ever; sn[n].attacked_since = r.since;
+            sn[n].discovered_props = r.props_tags & ROW_PROPS_MASK; sn[n].attacked_ever = r.ever; sn[n].attacked_since = r.since;
             sn[n].discovered = (mk[M_DISC][k] & bit) != 0; sn[n].installed = (mk[M_INST][k] & bit) != 0;
             sn[n].ever_owned = (mk[M_EVER][k] & bit) != 0; sn[n].running = (mk[M_RUN][k] & bit) != 0;
             sn[n].privilege = (uint8_t)(((mk[M_PLO][k] & bit) ? 1 : 0) | ((mk[M_PHI][k] & bit) ? 2 : 0));
-            sn[n].tags = (uint8_t)(r.tags & 0xFFu);
+            sn[n].tags = (uint8_t)(r.props_tags >> 60);
             sn[n].countdown = 0;
             if (!sn[n].running && ring) {   // remaining steps = distance from the defender clock to the node's ring slot
                 const uint32_t d = (h0[e].w >> 16) & 15u;

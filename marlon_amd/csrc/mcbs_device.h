@@ -28,14 +28,33 @@ constexpr int F_LEVEL_SHIFT = 8;     // 2 bits  last escalation level
 constexpr int F_NEWNODES_SHIFT = 12; // 10 bits newly discovered nodes of the last action
 constexpr int F_NEWCREDS_SHIFT = 22; // 10 bits credentials newly added to the cache by the last action
 
-struct Row {            // 32 bytes
-    uint64_t props;     // discovered properties
+struct Row {            // 16 bytes
+    uint64_t props_tags; // bits 0..59 discovered properties, bits 60..63 privilege_k tags appended to node.properties (actions.py:378)
     uint32_t ever;      // slot s exploited at least once            (actions.py:396-407)
     uint32_t since;     // ... and not re-imaged since
-    uint32_t tags;      // privilege_k tags appended to node.properties (actions.py:378), 4 bits
-    uint32_t spare[3];
 };
-static_assert(sizeof(Row) == 32, "row");
+static_assert(sizeof(Row) == 16, "row");
+constexpr uint64_t ROW_PROPS_MASK = (1ull << 60) - 1ull;
+
+// "Hot image": the part of the topology the step kernel reads, re-packed for it on the host at batch creation and
+// staged in LDS by every workgroup.  One 32-byte record per node and one 32-byte descriptor per (node, vulnerability
+// column): the slot_of -> slot indirection of the interchange blob is flattened away.
+struct HotNode {        // 32 bytes
+    uint64_t props;     // static properties that become known when the node is owned
+    int32_t  value;
+    uint32_t fw_in_allow, fw_out_allow, listen;
+    uint16_t svc_off, svc_cnt;
+    uint8_t  flags, pad[3];
+};
+struct HotDesc {        // 32 bytes; kind == 0xFF: the node does not have this vulnerability
+    double   cost;
+    uint64_t probe_mask;
+    uint32_t payload_off;
+    uint16_t payload_cnt, precond_tt;
+    uint8_t  kind, level, slot, pad;
+    uint32_t pad2;
+};
+static_assert(sizeof(HotNode) == 32 && sizeof(HotDesc) == 32, "hot records");
 
 // node-set and credential-set columns, [word][env] u64 each
 enum { M_DISC = 0, M_INST, M_EVER, M_RUN, M_PLO, M_PHI, M_GATH, M_CACH, M_COUNT };
@@ -55,8 +74,9 @@ struct DevState {
     uint32_t body_stride, off_disc, off_cred, off_rows, Cmax;
 };
 
-struct Topo {           // device view of the MCBT blob
+struct Topo {           // device view of the MCBT blob and of the hot image built from it
     const uint8_t* base;
+    const uint8_t* hot;
     __device__ __forceinline__ const mcbs_topo_header& H() const { return *reinterpret_cast<const mcbs_topo_header*>(base); }
 };
 
@@ -70,7 +90,8 @@ struct StepCfg {        // the parts of mcbs_batch_cfg the kernels read
     uint32_t L, R, P, V, n_props, K;
     // section offsets into the blob, hoisted so kernels do not chase the header
     uint32_t off_node, off_slot_of, off_slot, off_payload, off_service, off_allowed, off_triple;
-    uint32_t lds_bytes;  // bytes of the blob (header + tables up to the oracle byte code) staged in LDS
+    // hot image (Topo::hot) section offsets and size
+    uint32_t hot_node, hot_desc, hot_payload, hot_service, hot_allowed, hot_triple, hot_avail, hot_bytes;
 };
 
 struct StepIO {

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void obs_small_kernel(DevState S, Topo T, Step
         int32_t* out = O.props + (size_t)e * Nm * NP;
         for (uint32_t i = 0; i < Nm; ++i) {   // one discovered node per iteration, lanes over properties
             uint64_t pm = 0;
-            if (!blank && i < n_disc) pm = rows[dl[i]].props;
+            if (!blank && i < n_disc) pm = rows[dl[i]].props_tags & ROW_PROPS_MASK;
             for (uint32_t p = lane; p < NP; p += 64u) out[i * NP + p] = blank ? 2 : (int32_t)((pm >> p) & 1ull);
         }
     }

@@ -75,23 +75,21 @@ template <int WT>
 struct Lane {
     const DevState& S;
     const StepCfg& C;
-    const uint8_t* tb;   // topology tables (LDS copy or the blob in global memory)
+    const uint8_t* tb;   // hot image (LDS copy, or Topo::hot in global memory)
     uint32_t e;
     uint8_t* body;
     uint32_t n_disc, n_creds, owned, dclk;
     uint64_t m[M_COUNT][WT];
     uint32_t dirty;      // bit k: set k changed and must be written back
     // the target node's row, in registers
-    uint64_t props;
+    uint64_t props;      // discovered properties (60 bits)
     uint32_t ever, since, tags;
     bool row_dirty;
     // result of the attacker's action
     double raw;
     int okind, olevel, new_nodes, new_creds;
 
-    __device__ __forceinline__ const mcbs_node_static* NS(uint32_t n) const {
-        return reinterpret_cast<const mcbs_node_static*>(tb + C.off_node) + n;
-    }
+    __device__ __forceinline__ const HotNode* NS(uint32_t n) const { return reinterpret_cast<const HotNode*>(tb + C.hot_node) + n; }
     __device__ __forceinline__ Row* row(uint32_t n) const { return reinterpret_cast<Row*>(body + S.off_rows) + n; }
     __device__ __forceinline__ uint8_t* disc_list() const { return body + S.off_disc; }
     __device__ __forceinline__ uint16_t* cred_list() const { return reinterpret_cast<uint16_t*>(body + S.off_cred); }
@@ -106,65 +104,104 @@ struct Lane {
         dirty |= (1u << M_PLO) | (1u << M_PHI);
     }
 
-    // __mark_node_as_owned (actions.py:251-275).  Returns "was owned at some point before" (last_owned_at is not
-    // None); `already` = currently owned (agent_installed, see the header comment on logical time).
-    __device__ __forceinline__ bool mark_owned(uint32_t n, uint32_t level, bool& already) {
-        already = rget<WT>(m[M_INST], n);
-        if (already) return true;                                   // currently owned implies owned before
-        const bool ever_owned = rtestset<WT>(m[M_EVER], n);
-        rset<WT>(m[M_INST], n);
-        dirty |= (1u << M_EVER) | (1u << M_INST);
-        const uint32_t priv = privilege(n);
-        const uint32_t np = priv > level ? priv : level;           // model.escalate
-        if (np != priv) {
-            set_privilege(n, np);
-            if (priv == 0u) owned += 1;
+    // One action of one env: AgentActions.exploit_local_vulnerability / exploit_remote_vulnerability (actions.py:473-502,
+    // 425-471) -> __process_outcome (325-423) with __mark_discovered_entities (277-310), and connect_to_remote_machine
+    // (524-606), merged into one flow so that the ownership change (__mark_node_as_owned, 251-275) and the bookkeeping
+    // exist once in the instruction stream: lanes of a wavefront hold different action kinds and every divergent copy
+    // of a block is paid by the whole wave.  kind: 0 local, 1 remote, 2 connect; `col` = vulnerability column (exploits),
+    // `port` / `triple` = connect arguments.
+    __device__ __forceinline__ void act(int kind, uint32_t src, uint32_t tgt, uint32_t col, uint32_t port, uint32_t triple) {
+        // Phase A — every check of the reference, evaluated without early exits and folded by priority into
+        // (proceed, raw, okind): keeps the wavefront's control flow two levels deep instead of one level per check.
+        const HotNode* t = NS(tgt);
+        const bool src_owned = rget<WT>(m[M_INST], src);
+        const bool running = rget<WT>(m[M_RUN], tgt);
+        bool proceed, want_own = false;
+        uint32_t own_level = 1u, slot_bit = 0u, payload_off = 0u, payload_cnt = 0u, okind_ok = MCBS_OUT_LATERAL_MOVE;
+        uint64_t probe = 0ull;
+        double cost = 0.0, fail_raw;
+        int fail_kind = MCBS_OUT_NONE, lvl_out = 0;
+        if (kind == 2) {
+            // target is discovered and the credential gathered by construction (both come from this env's own lists)
+            const uint32_t cred = (reinterpret_cast<const mcbs_triple*>(tb + C.hot_triple) + triple)->cred;
+            const bool fw_ok = ((NS(src)->fw_out_allow >> port) & 1u) && ((t->fw_in_allow >> port) & 1u);  // BLOCKED_BY_LOCAL/REMOTE_FIREWALL
+            const bool listening = (t->listen >> port) & 1u;                                              // SCANNING_UNOPEN_PORT
+            bool authorized = false;                                                                      // actions.py:608-621
+            const mcbs_service* sv = reinterpret_cast<const mcbs_service*>(tb + C.hot_service) + t->svc_off;
+            const uint16_t* allowed = reinterpret_cast<const uint16_t*>(tb + C.hot_allowed);
+            const uint32_t nsv = t->svc_cnt;
+            for (uint32_t i = 0; i < nsv; ++i) {
+                const bool match = sv[i].running && sv[i].port == port;
+                const uint32_t ao = sv[i].allowed_off, ac = match ? sv[i].allowed_cnt : 0u;
+                for (uint32_t k = 0; k < ac; ++k) authorized |= (allowed[ao + k] == cred);
+            }
+            // order of the reference: firewalls (-10), listening (-10), running (0), credentials (-10: WRONG_PASSWORD)
+            proceed = fw_ok && listening && running && authorized;
+            fail_raw = (fw_ok && listening && !running) ? 0.0 : -10.0;
+            want_own = true;
+        } else {
+            const uint4* dp = reinterpret_cast<const uint4*>(tb + C.hot_desc + (tgt * (C.L + C.R) + col) * (uint32_t)sizeof(HotDesc));
+            const uint4 d0 = dp[0], d1 = dp[1];   // {cost lo,hi, probe lo,hi} {payload_off, cnt | tt << 16, kind | level << 8 | slot << 16, -}
+            const uint32_t vk = d1.z & 0xFFu, level = (d1.z >> 8) & 0xFFu;
+            const bool present = vk != 0xFFu;
+            const bool pre_ok = ((d1.y >> 16) >> tags) & 1u;                                              // precondition on (static props, tags)
+            const bool esc = vk == MCBS_OUT_PRIVILEGE_ESCALATION;
+            const bool repeat_esc = esc && ((tags >> level) & 1u);                                        // tag already on the node
+            proceed = running && present && pre_ok && !repeat_esc;
+            // MACHINE_NOT_RUNNING 0 > SUPSPICIOUSNESS -5 > LOCAL_EXPLOIT_FAILED -20 / FAILED_REMOTE_EXPLOIT -50 > REPEAT -1
+            fail_raw = !running ? 0.0 : (!present ? -5.0 : (!pre_ok ? (kind == 0 ? -20.0 : -50.0) : -1.0));
+            fail_kind = (running && present) ? (!pre_ok ? MCBS_OUT_EXPLOIT_FAILED : MCBS_OUT_PRIVILEGE_ESCALATION) : MCBS_OUT_NONE;
+            lvl_out = (running && present && pre_ok && esc) ? (int)level : 0;
+            okind_ok = vk;
+            want_own = esc || vk == MCBS_OUT_LATERAL_MOVE;
+            own_level = esc ? level : 1u;
+            probe = vk == MCBS_OUT_PROBE_SUCCEEDED ? ((uint64_t)d0.z | ((uint64_t)d0.w << 32)) : 0ull;
+            slot_bit = 1u << ((d1.z >> 16) & 0x1Fu);
+            payload_off = d1.x; payload_cnt = d1.y & 0xFFFFu;
+            cost = __hiloint2double((int)d0.y, (int)d0.x);
         }
-        props |= NS(n)->props;                                      // all (non-tag) properties become known
-        row_dirty = true;
-        return ever_owned;
-    }
+        if (!src_owned) return done_with(-1.0, MCBS_OUT_NONE);                                            // INVALID_ACTION, checked first
+        olevel = lvl_out;
+        if (!proceed) return done_with(fail_raw, fail_kind);
 
-    // __process_outcome (actions.py:325-423) with __mark_discovered_entities (277-310) and the env-side
-    // appends of cyberbattle_env.py:863-907 fused (both sides keep the same sets, in the same order).
-    __device__ __forceinline__ void process_outcome(uint32_t tgt, uint32_t col, double failed_penalty) {
-        if (!rget<WT>(m[M_RUN], tgt)) return done_with(0.0, MCBS_OUT_NONE);                   // MACHINE_NOT_RUNNING
-        const uint32_t s = (tb + C.off_slot_of)[tgt * (C.L + C.R) + col];
-        if (s == 0xFFu) return done_with(-5.0, MCBS_OUT_NONE);                               // SUPSPICIOUSNESS
-        const uint4* vp = reinterpret_cast<const uint4*>(tb + C.off_slot + (tgt * C.V + s) * (uint32_t)sizeof(mcbs_vuln_slot));
-        const uint4 v0 = vp[0], v1 = vp[1];   // {cost lo,hi, probe lo,hi} {payload_off, cnt | tt << 16, code_off, code_len | kind << 16 | level << 24}
-        const uint32_t kind = (v1.w >> 16) & 0xFFu, level = v1.w >> 24;
-        if (!(((v1.y >> 16) >> tags) & 1u)) return done_with(failed_penalty, MCBS_OUT_EXPLOIT_FAILED);
-
+        // Phase B — __mark_node_as_owned (actions.py:251-275): `already` = currently owned (agent installed); a node that
+        // is owned now was owned before, so only a change of ownership consults / sets the ever-owned bit
         int r = 0;
-        if (kind == MCBS_OUT_PRIVILEGE_ESCALATION) {
-            olevel = (int)level;
-            if ((tags >> level) & 1u) return done_with(-1.0, MCBS_OUT_PRIVILEGE_ESCALATION);  // REPEAT, nothing recorded
-            bool already;
-            if (!mark_owned(tgt, level, already)) r += NS(tgt)->value;
-            tags |= 1u << level;
-        } else if (kind == MCBS_OUT_LATERAL_MOVE) {
-            bool already;
-            if (!mark_owned(tgt, 1u, already)) r += NS(tgt)->value;
-        } else if (kind == MCBS_OUT_PROBE_SUCCEEDED) {
-            const uint64_t pm = (uint64_t)v0.z | ((uint64_t)v0.w << 32);
-            r += 2 * __popcll(pm & ~props);
-            props |= pm;
+        if (want_own) {
+            const bool already = rget<WT>(m[M_INST], tgt);
+            bool owned_before = true;
+            if (!already) {
+                owned_before = rtestset<WT>(m[M_EVER], tgt);
+                rset<WT>(m[M_INST], tgt);
+                dirty |= (1u << M_EVER) | (1u << M_INST);
+                const uint32_t priv = privilege(tgt);
+                const uint32_t np = priv > own_level ? priv : own_level;   // model.escalate
+                if (np != priv) { set_privilege(tgt, np); if (priv == 0u) owned += 1; }
+                props |= t->props;                                          // all (non-tag) properties become known
+                row_dirty = true;
+            }
+            if (kind == 2) {
+                if (already) return done_with(-1.0, MCBS_OUT_LATERAL_MOVE);                        // REPEAT
+                return done_with(owned_before ? 0.0 : (double)t->value, MCBS_OUT_LATERAL_MOVE);
+            }
+            if (!owned_before) r += t->value;
+            if (okind_ok == MCBS_OUT_PRIVILEGE_ESCALATION) tags |= 1u << own_level;
         }
-        const uint32_t bit = 1u << s;
-        if (ever & bit) { if (since & bit) r -= 1; } else r += 7;
-        ever |= bit; since |= bit;
+        // Phase C — exploit bookkeeping (actions.py:386-423)
+        r += 2 * __popcll(probe & ~props);
+        props |= probe;
+        if (ever & slot_bit) { if (since & slot_bit) r -= 1; } else r += 7;
+        ever |= slot_bit; since |= slot_bit;
         row_dirty = true;
-
         int nn = 0, nc = 0;
-        if (kind == MCBS_OUT_LEAKED_CREDENTIALS || kind == MCBS_OUT_LEAKED_NODES) {
-            const uint32_t cnt = v1.y & 0xFFFFu;
-            const uint2* pl = reinterpret_cast<const uint2*>(tb + C.off_payload) + v1.x;
-            for (uint32_t i = 0; i < cnt; ++i) {
+        const bool creds = okind_ok == MCBS_OUT_LEAKED_CREDENTIALS;
+        if (creds || okind_ok == MCBS_OUT_LEAKED_NODES) {
+            const uint2* pl = reinterpret_cast<const uint2*>(tb + C.hot_payload) + payload_off;
+            for (uint32_t i = 0; i < payload_cnt; ++i) {
                 const uint2 p = pl[i];                   // {node | cred << 16, triple | port << 16}
                 const uint32_t pn = p.x & 0xFFFFu;
                 if (!rtestset<WT>(m[M_DISC], pn)) { disc_list()[n_disc++] = (uint8_t)pn; nn++; dirty |= 1u << M_DISC; }
-                if (kind == MCBS_OUT_LEAKED_CREDENTIALS) {
+                if (creds) {
                     if (!rtestset<WT>(m[M_GATH], p.x >> 16)) { nc++; dirty |= 1u << M_GATH; }
                     if (!rtestset<WT>(m[M_CACH], p.y & 0xFFFFu)) {
                         cred_list()[n_creds++] = (uint16_t)(p.y & 0xFFFFu); new_creds++; dirty |= 1u << M_CACH;
@@ -174,34 +211,7 @@ struct Lane {
         }
         new_nodes = nn;
         r += 5 * nn + 3 * nc;
-        const double cost = __hiloint2double((int)v0.y, (int)v0.x);
-        done_with((double)r - cost, (int)kind);
-    }
-
-    // connect_to_remote_machine (actions.py:524-606); the credential index was checked against the cache length
-    __device__ __forceinline__ void connect(uint32_t src, uint32_t tgt, uint32_t port, uint32_t triple) {
-        if (!rget<WT>(m[M_INST], src)) return done_with(-1.0, MCBS_OUT_NONE);
-        // target is discovered and the credential gathered by construction (both come from this env's own lists)
-        const uint32_t cred = (reinterpret_cast<const mcbs_triple*>(tb + C.off_triple) + triple)->cred;
-        const mcbs_node_static* t = NS(tgt);
-        if (!((NS(src)->fw_out_allow >> port) & 1u)) return done_with(-10.0, MCBS_OUT_NONE);  // BLOCKED_BY_LOCAL_FIREWALL
-        if (!((t->fw_in_allow >> port) & 1u)) return done_with(-10.0, MCBS_OUT_NONE);         // BLOCKED_BY_REMOTE_FIREWALL
-        if (!((t->listen >> port) & 1u)) return done_with(-10.0, MCBS_OUT_NONE);              // SCANNING_UNOPEN_PORT
-        if (!rget<WT>(m[M_RUN], tgt)) return done_with(0.0, MCBS_OUT_NONE);                    // MACHINE_NOT_RUNNING
-        bool authorized = false;                                                              // actions.py:608-621
-        const mcbs_service* sv = reinterpret_cast<const mcbs_service*>(tb + C.off_service) + t->svc_off;
-        const uint16_t* allowed = reinterpret_cast<const uint16_t*>(tb + C.off_allowed);
-        const uint32_t nsv = t->svc_cnt;
-        for (uint32_t i = 0; i < nsv; ++i) {
-            if (!sv[i].running || sv[i].port != port) continue;
-            const uint32_t ao = sv[i].allowed_off, ac = sv[i].allowed_cnt;
-            for (uint32_t k = 0; k < ac; ++k) authorized |= (allowed[ao + k] == cred);
-        }
-        if (!authorized) return done_with(-10.0, MCBS_OUT_NONE);                              // WRONG_PASSWORD
-        bool already;
-        const bool ever_owned = mark_owned(tgt, 1u, already);
-        if (already) return done_with(-1.0, MCBS_OUT_LATERAL_MOVE);                            // REPEAT
-        done_with(ever_owned ? 0.0 : (double)t->value, MCBS_OUT_LATERAL_MOVE);
+        done_with((double)r - cost, (int)okind_ok);
     }
 
     // ---- defender ----
@@ -218,6 +228,7 @@ struct Lane {
         const uint32_t rem = S.N - w * 64u;
         return rem >= 64u ? ~0ull : ((1ull << rem) - 1ull);
     }
+    __device__ __forceinline__ double avail_term(uint32_t n) const { return reinterpret_cast<const double*>(tb + C.hot_avail)[n]; }
 
     // on_attacker_step_taken (actions.py:714-746): nodes whose re-imaging started 16 defender ticks ago are back
     // (REIMAGING_DURATION 15 -> 0, then Running); `back` = this tick's ring slot.  Returns the availability.
@@ -235,11 +246,11 @@ struct Lane {
 #pragma unroll
             for (int w = 0; w < WT; ++w) {
                 uint64_t im = ~m[M_RUN][w] & valid_bits(w);
-                while (im) { const uint32_t b = (uint32_t)__builtin_ctzll(im); im &= im - 1; s -= NS(w * 64u + b)->avail_term; }
+                while (im) { const uint32_t b = (uint32_t)__builtin_ctzll(im); im &= im - 1; s -= avail_term(w * 64u + b); }
             }
         } else {                          // the reference's node-order sum
             s = 0.0;
-            for (uint32_t n = 0; n < S.N; ++n) if (rget<WT>(m[M_RUN], n)) s += NS(n)->avail_term;
+            for (uint32_t n = 0; n < S.N; ++n) if (rget<WT>(m[M_RUN], n)) s += avail_term(n);
         }
         return s / C.total_sla_weight;
     }
@@ -270,7 +281,8 @@ struct Lane {
 // PHASE 2: defender, goals, outputs, auto-reset (after the observation kernels ran).
 // WT: words per set held in registers (1, 2 or 4; >= NW, SW, TW).  TOPO_LDS: topology tables staged in LDS.
 template <int PHASE, int WT, bool TOPO_LDS, bool DEF>
-__global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, StepCfg C, StepIO io) {
+__global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, const StepCfg* __restrict__ Cp, StepIO io) {
+    const StepCfg& C = *Cp;   // in device memory: fields are fetched by scalar loads where they are used, not all up front
     extern __shared__ uint4 topo_lds[];
 #ifdef MCBS_DIAG
     unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -315,10 +327,10 @@ __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, StepCfg C
     }
 
     STAMP_NOWAIT(1);   // level-1 loads issued
-    const uint8_t* tb = T.base;
-    if (TOPO_LDS) {                                     // cooperative copy of the topology tables, 16 bytes per lane
-        const uint4* src = reinterpret_cast<const uint4*>(T.base);
-        for (uint32_t i = threadIdx.x; i < C.lds_bytes / 16u; i += blockDim.x) topo_lds[i] = src[i];
+    const uint8_t* tb = T.hot;
+    if (TOPO_LDS) {                                     // cooperative copy of the hot topology image, 16 bytes per lane
+        const uint4* src = reinterpret_cast<const uint4*>(T.hot);
+        for (uint32_t i = threadIdx.x; i < C.hot_bytes / 16u; i += blockDim.x) topo_lds[i] = src[i];
         __syncthreads();
         tb = reinterpret_cast<const uint8_t*>(topo_lds);
     }
@@ -379,25 +391,22 @@ __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, StepCfg C
                 const uint32_t src = node_of(a1);
                 const uint32_t tgt = kind == 0 ? src : node_of(a2);
                 // ---------------- level 2: the target row ----------------
-                const Row* rp = ln.row(tgt);
-                const uint4 r0 = *reinterpret_cast<const uint4*>(rp);
-                ln.tags = rp->tags;
-                ln.props = (uint64_t)r0.x | ((uint64_t)r0.y << 32);
+                const uint4 r0 = *reinterpret_cast<const uint4*>(ln.row(tgt));
+                const uint64_t pt = (uint64_t)r0.x | ((uint64_t)r0.y << 32);
+                ln.props = pt & ROW_PROPS_MASK; ln.tags = (uint32_t)(pt >> 60);
                 ln.ever = r0.z; ln.since = r0.w;
                 STAMP(3);  // row landed
+                uint32_t triple = 0;
                 if (kind == 2) {
-                    uint32_t triple;
                     if (a4i < 16) {
                         const uint32_t d = a4i < 8 ? pick4(chead0, (uint32_t)a4i >> 1) : pick4(chead1, ((uint32_t)a4i - 8u) >> 1);
                         triple = (d >> (16u * ((uint32_t)a4i & 1u))) & 0xFFFFu;
                     } else triple = ln.cred_list()[a4i];
-                    ln.connect(src, tgt, (uint32_t)a3, triple);
-                } else if (!rget<WT>(ln.m[M_INST], src)) ln.done_with(-1.0, MCBS_OUT_NONE);       // INVALID_ACTION
-                else ln.process_outcome(tgt, kind == 0 ? (uint32_t)a2 : C.L + (uint32_t)a3, kind == 0 ? -20.0 : -50.0);
+                }
+                ln.act(kind, src, tgt, kind == 0 ? (uint32_t)a2 : C.L + (uint32_t)a3, (uint32_t)a3, triple);
                 if (ln.row_dirty) {
-                    Row* wp = ln.row(tgt);
-                    *reinterpret_cast<uint4*>(wp) = make_uint4((uint32_t)ln.props, (uint32_t)(ln.props >> 32), ln.ever, ln.since);
-                    wp->tags = ln.tags;
+                    const uint64_t wpt = ln.props | ((uint64_t)ln.tags << 60);
+                    *reinterpret_cast<uint4*>(ln.row(tgt)) = make_uint4((uint32_t)wpt, (uint32_t)(wpt >> 32), ln.ever, ln.since);
                 }
             }
             STAMP(4);      // attacker logic and row store done

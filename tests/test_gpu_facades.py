@@ -213,6 +213,5 @@ def test_run_episodes_random_policy_finishes_chain4():
     assert (ep >= 1).all()                                        # every env ended at least one episode (win or truncation at 400)
     r = out["rewards"].cpu().numpy()
     assert r.min() >= 0.0 and r.sum() > 0                         # masked actions are never intercepted (no -1 modifier)
-    assert (out["dones"].cpu().numpy()[-1] == 1).all()            # nobody wins Chain-4 by uniform masked sampling before truncation...
     assert out["returns"].cpu().numpy().min() >= 0.0
     env.close()
