@@ -433,6 +433,30 @@ static int launch_region(mcbs_batch* b, int8_t* dst, size_t env_stride, size_t r
     const size_t chunks = (len + W - 1) / W;
     const dim3 grid(b->S.E, (unsigned)((chunks + 255) / 256));
     if (grid.y > 65535u) return fail(MCBS_ELIMIT, "mask region too large for one launch");
+    const uint32_t RL = REGION == 0 ? b->C.P * Cm : (REGION == 1 ? Nm * b->C.R : 0u), Cc = REGION == 0 ? Cm : RL;
+    if (W == 16 && REGION != 2 && RL >= 16u && len < (1ull << 31) && !getenv("MCBS_SLOW_MASKS")) {
+        auto fd = [](uint32_t d) {   // n / d = (t + ((n - t) >> sh1)) >> sh2 with t = mulhi(n, mul)
+            uint32_t l = 0;
+            while ((1ull << l) < d) ++l;
+            FastDiv f;
+            f.mul = (uint32_t)(((1ull << 32) * ((1ull << l) - d)) / d + 1ull);
+            f.sh1 = l < 1u ? l : 1u;
+            f.sh2 = l > 0u ? l - 1u : 0u;
+            return f;
+        };
+        const uint32_t flat = chunks < 256 && (uint64_t)chunks * b->S.E < (1ull << 31) ? 1u : 0u;
+        uint32_t gx = (uint32_t)((chunks + 1023) / 1024 < 8 ? (chunks + 1023) / 1024 : 8);
+        uint32_t gy = 4096u / gx;
+        if (gy > b->S.E) gy = b->S.E;
+        if (flat) { gx = 1; gy = (uint32_t)(((uint64_t)chunks * b->S.E + 255) / 256 < 4096 ? ((uint64_t)chunks * b->S.E + 255) / 256 : 4096); }
+        const dim3 fgrid(gx, gy);
+#define MCBS_LAUNCH_FAST(REG_, FLAT_) hipLaunchKernelGGL((mask_fast_kernel<REG_, FLAT_>), fgrid, dim3(256), 0, st, b->S, b->digest, dst, env_stride, \
+        region_off, (uint32_t)len, RL, Cc, Nm, b->C.R, fd(RL), fd(Cc), fd(Nm), env_mask, masks_only ? 0u : 1u, fd((uint32_t)chunks))
+        if (REGION == 0) { if (flat) MCBS_LAUNCH_FAST(0, true); else MCBS_LAUNCH_FAST(0, false); }
+        else { if (flat) MCBS_LAUNCH_FAST(1, true); else MCBS_LAUNCH_FAST(1, false); }
+#undef MCBS_LAUNCH_FAST
+        return launch_ok("mask (fast)");
+    }
     if (W == 16) hipLaunchKernelGGL((mask_kernel<16, REGION>), grid, dim3(256), 0, st, b->S, b->T, b->C, b->digest, dst, env_stride, region_off, Nm, Cm, env_mask, masks_only ? 0u : 1u);
     else if (W == 4) hipLaunchKernelGGL((mask_kernel<4, REGION>), grid, dim3(256), 0, st, b->S, b->T, b->C, b->digest, dst, env_stride, region_off, Nm, Cm, env_mask, masks_only ? 0u : 1u);
     else hipLaunchKernelGGL((mask_kernel<1, REGION>), grid, dim3(256), 0, st, b->S, b->T, b->C, b->digest, dst, env_stride, region_off, Nm, Cm, env_mask, masks_only ? 0u : 1u);

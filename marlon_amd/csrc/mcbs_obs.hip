@@ -193,6 +193,84 @@ __global__ __launch_bounds__(256) void mask_kernel(DevState S, Topo T, StepCfg C
     else out[0] = v[0];
 }
 
+// ---- fast path of the two big masks (16-byte stores) -------------------------------------------------------------
+// Both masks are periodic: connect[s][t][p][c] = own(s) && t < n_disc && c < n_creds is, per (s,t) row of RL = P*C
+// bytes, the pattern "n_creds ones, C - n_creds zeros" repeated; because every row length is a multiple of C the
+// pattern depends only on (byte index mod C) across the whole env, and rows only switch it on or off.
+// remote[s][t][r] = own(s) && t < n_disc is, per source row of RL = N*R bytes, "n_disc*R ones then zeros" (C = RL).
+// A thread therefore builds its 16 bytes from two byte-range masks instead of walking them one by one.
+struct FastDiv { uint32_t mul, sh1, sh2; };   // n / d for 32-bit n (Granlund-Montgomery round-up form), set up on the host
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv d) {
+    const uint32_t t = __umulhi(n, d.mul);
+    return (t + ((n - t) >> d.sh1)) >> d.sh2;
+}
+__device__ __forceinline__ void ones_upto(uint32_t k, uint64_t& lo, uint64_t& hi) {   // bytes [0,k) = 0xFF, k in 0..16
+    lo = k >= 8u ? ~0ull : (k ? (~0ull >> (64u - 8u * k)) : 0ull);
+    hi = k <= 8u ? 0ull : (k >= 16u ? ~0ull : (~0ull >> (64u - 8u * (k - 8u))));
+}
+
+// 16 bytes of one env's periodic mask starting at byte idx0 (multiple of 16)
+template <int REGION>
+__device__ __forceinline__ uint4 mask_chunk(const ObsDigest& d, uint32_t ones, uint32_t idx0, uint32_t RL, uint32_t Cc, uint32_t Nm,
+                                            FastDiv dRL, FastDiv dC, FastDiv dN) {
+    const uint32_t q0 = fdiv(idx0, dRL), r0 = idx0 - q0 * RL;
+    uint32_t c = REGION == 0 ? r0 - fdiv(r0, dC) * Cc : r0;
+    auto row_on = [&](uint32_t q) -> bool {
+        uint32_t s = q, t = 0;
+        if (REGION == 0) { s = fdiv(q, dN); t = q - s * Nm; }
+        return s < Nm && ((d.own_ext[(s >> 6) & 3u] >> (s & 63u)) & 1ull) && (REGION == 1 || t < d.n_disc);
+    };
+    uint64_t plo = 0, phi = 0;                 // which of the 16 bytes are 1 inside an "on" row
+    for (uint32_t pos = 0; pos < 16u;) {
+        const uint32_t seg = min(16u - pos, Cc - c);
+        const uint32_t k = c < ones ? min(ones - c, seg) : 0u;
+        uint64_t alo, ahi, blo, bhi;
+        ones_upto(pos + k, alo, ahi);
+        ones_upto(pos, blo, bhi);
+        plo |= alo & ~blo; phi |= ahi & ~bhi;
+        pos += seg; c = 0;
+    }
+    const uint32_t b = min(16u, RL - r0);      // bytes of row q0 in this chunk; the rest belongs to row q0 + 1 (RL >= 16)
+    uint64_t flo, fhi;
+    ones_upto(b, flo, fhi);
+    const bool on0 = row_on(q0), on1 = b < 16u && row_on(q0 + 1u);
+    const uint64_t mlo = (on0 ? flo : 0ull) | (on1 ? ~flo : 0ull), mhi = (on0 ? fhi : 0ull) | (on1 ? ~fhi : 0ull);
+    const uint64_t lo = plo & mlo & 0x0101010101010101ull, hi = phi & mhi & 0x0101010101010101ull;
+    return make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+}
+
+// FLAT = false: blockIdx.y strides over envs (digest and flags read once per env), threads stride over the env's chunks.
+// FLAT = true : regions shorter than a workgroup's reach (remote: N*N*R bytes): one flat (env, chunk) index.
+// Either way a few thousand workgroups stream the whole [E, len] array.
+template <int REGION, bool FLAT>   // REGION 0 connect, 1 remote
+__global__ __launch_bounds__(256) void mask_fast_kernel(DevState S, const ObsDigest* digest, int8_t* dst, size_t env_stride,
+                                                        size_t region_off, uint32_t len, uint32_t RL, uint32_t Cc, uint32_t Nm,
+                                                        uint32_t Rr, FastDiv dRL, FastDiv dC, FastDiv dN, const uint8_t* env_mask,
+                                                        uint32_t skip_flagged, FastDiv dCPE) {
+    const uint32_t cpe = len / 16u;          // 16-byte chunks per env
+    if (FLAT) {
+        const uint32_t nthreads = gridDim.x * gridDim.y * blockDim.x, total = S.E * cpe;
+        for (uint32_t g = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; g < total; g += nthreads) {
+            const uint32_t e = fdiv(g, dCPE), idx0 = (g - e * cpe) * 16u;
+            if (env_mask && !env_mask[e]) continue;
+            if (skip_flagged && (S.h0[e].y & F_SKIP)) continue;
+            const ObsDigest d = digest[e];
+            const uint32_t ones = REGION == 0 ? d.n_creds : d.n_disc * Rr;
+            *reinterpret_cast<uint4*>(dst + (size_t)e * env_stride + region_off + idx0) = mask_chunk<REGION>(d, ones, idx0, RL, Cc, Nm, dRL, dC, dN);
+        }
+    } else {
+        for (uint32_t e = blockIdx.y; e < S.E; e += gridDim.y) {
+            if (env_mask && !env_mask[e]) continue;
+            if (skip_flagged && (S.h0[e].y & F_SKIP)) continue;
+            const ObsDigest d = digest[e];
+            const uint32_t ones = REGION == 0 ? d.n_creds : d.n_disc * Rr;     // leading ones of one period
+            int8_t* out = dst + (size_t)e * env_stride + region_off;
+            for (uint32_t idx0 = (blockIdx.x * blockDim.x + threadIdx.x) * 16u; idx0 < len; idx0 += gridDim.x * blockDim.x * 16u)
+                *reinterpret_cast<uint4*>(out + idx0) = mask_chunk<REGION>(d, ones, idx0, RL, Cc, Nm, dRL, dC, dN);
+        }
+    }
+}
+
 #define MCBS_INST(W) \
     template __global__ void mask_kernel<W, 0>(DevState, Topo, StepCfg, const ObsDigest*, int8_t*, size_t, size_t, uint32_t, uint32_t, const uint8_t*, uint32_t); \
     template __global__ void mask_kernel<W, 1>(DevState, Topo, StepCfg, const ObsDigest*, int8_t*, size_t, size_t, uint32_t, uint32_t, const uint8_t*, uint32_t); \
