@@ -39,7 +39,7 @@ B_STEP = 348            # algorithmic bytes per env-step, SURVEY.md section 8(d)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 
-def build_engine(rank: int, n_envs: int, max_episode_steps: int):
+def build_engine(rank: int, local_rank: int, n_envs: int, max_episode_steps: int):
     from marlon_amd import engine, flatten
     from marlon_amd._abi import EnvSpec
     from marlon_amd.samples import chainpattern
@@ -47,8 +47,8 @@ def build_engine(rank: int, n_envs: int, max_episode_steps: int):
     topo = flatten.flatten(chainpattern.new_environment(10))
     spec = EnvSpec(n_envs=n_envs, maximum_node_count=12, maximum_total_credentials=12,
                    attacker_goal=dict(own_atleast_percent=1.0), auto_reset=True,
-                   max_episode_steps=max_episode_steps, seed=12345, env_id_base=rank * n_envs)
-    return engine.BatchEngine(topo, spec), topo, spec
+                   max_episode_steps=max_episode_steps, seed=12345, env_id_base=rank * n_envs, device=local_rank)
+    return engine.BatchEngine(topo, spec, device=f"cuda:{local_rank}"), topo, spec
 
 
 def main() -> int:
@@ -61,6 +61,9 @@ def main() -> int:
     ap.add_argument("--cpu-envs", type=int, default=8192)
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of a hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse the "
+                    "multi-rank code path on a single-GPU box together with --single-device)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
 
     import numpy as np
@@ -74,9 +77,15 @@ def main() -> int:
         if world == 1 and args.gpus > 1:
             print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
             return 2
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(args.backend)
+    coll_dev = torch.device(f"cuda:{local_rank}") if args.backend == "nccl" else torch.device("cpu")
 
     def barrier():
         if world > 1:
@@ -84,8 +93,7 @@ def main() -> int:
 
     E, K, W = args.envs_per_gpu, args.steps, args.warmup
     from marlon_amd._abi import EnvSpec  # noqa: F401
-    eng, topo, spec = build_engine(rank, E, args.max_episode_steps)
-    spec.device = local_rank
+    eng, topo, spec = build_engine(rank, local_rank, E, args.max_episode_steps)
     dev = eng.device
 
     # ---- untimed: record W+K batches of valid random actions into an HBM ring, then rewind ----
@@ -138,7 +146,7 @@ def main() -> int:
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -160,8 +168,9 @@ def main() -> int:
 
     # ---- optional logging collective (not on the data path): episode returns of every rank ----
     if world > 1:
-        gathered = [torch.empty_like(reward_sum_timed) for _ in range(world)]
-        dist.all_gather(gathered, reward_sum_timed)
+        mine = reward_sum_timed.to(coll_dev)
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
 
     result = None
     if rank == 0:
