@@ -592,8 +592,76 @@ extern "C" int mcbs_get_state(mcbs_batch* b, void* host_buf, size_t nbytes) {
 }
 
 extern "C" int mcbs_set_state(mcbs_batch* b, const void* host_buf, size_t nbytes) {
-    (void)b; (void)host_buf; (void)nbytes;
-    return fail(MCBS_ESTATE, "mcbs_set_state is not implemented in this round");
+    if (!b || !host_buf) return fail(MCBS_EINVAL, "null argument");
+    const size_t rb = mcbs_state_record_bytes(b);
+    const DevState& S = b->S;
+    if (nbytes < rb * S.E) return fail(MCBS_EINVAL, "state buffer too small: need %zu bytes", rb * S.E);
+    const mcbs_topo_header* th = b->topo->H();
+    HIP_TRY(hipSetDevice(b->cfg.device));
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<uint8_t> host(b->arena_bytes);
+    HIP_TRY(hipMemcpy(host.data(), b->arena, b->arena_bytes, hipMemcpyDeviceToHost));   // keeps init image, digest, episode
+    auto at = [&](const void* devptr) { return host.data() + (static_cast<const uint8_t*>(devptr) - b->arena); };
+    uint4* h0 = reinterpret_cast<uint4*>(at(S.h0));
+    double2* h1 = reinterpret_cast<double2*>(at(S.h1));
+    uint32_t* ep = reinterpret_cast<uint32_t*>(at(S.episode));
+    uint64_t* mk[M_COUNT];
+    for (int k = 0; k < M_COUNT; ++k) mk[k] = reinterpret_cast<uint64_t*>(at(S.mask(k)));
+    uint64_t* ring = S.ring ? reinterpret_cast<uint64_t*>(at(S.ring)) : nullptr;
+    uint8_t* body = at(S.body);
+    const mcbs_triple* tr = reinterpret_cast<const mcbs_triple*>(b->topo->host.data() + th->off_triple);
+    for (uint32_t e = 0; e < S.E; ++e) {
+        const uint8_t* p = static_cast<const uint8_t*>(host_buf) + rb * e;
+        const mcbs_state_header* sh = reinterpret_cast<const mcbs_state_header*>(p);
+        const mcbs_state_node* sn = reinterpret_cast<const mcbs_state_node*>(p + sizeof(mcbs_state_header));
+        const uint16_t* order = reinterpret_cast<const uint16_t*>(p + sizeof(mcbs_state_header) + sizeof(mcbs_state_node) * S.N);
+        const uint16_t* cc = order + S.N;
+        if (sh->n_discovered > S.N || sh->n_creds > th->n_triples) return fail(MCBS_EINVAL, "env %u: list lengths out of range", e);
+        for (uint32_t w = 0; w < S.WT; ++w) {
+            for (int k = 0; k < M_COUNT; ++k) mk[k][(size_t)w * S.E + e] = 0;
+            if (ring) for (uint32_t s = 0; s < 16u; ++s) ring[((size_t)s * S.WT + w) * S.E + e] = 0;
+        }
+        uint8_t* eb = body + (size_t)e * S.body_stride;
+        uint32_t owned = 0;
+        const uint32_t dclk = h0[e].w >> 16;      // the defender clock is not part of the canonical record: keep the current phase
+        for (uint32_t n = 0; n < S.N; ++n) {
+            const size_t k = (size_t)(n >> 6) * S.E + e;
+            const uint64_t bit = 1ull << (n & 63u);
+            if (sn[n].privilege > 3 || sn[n].countdown > 15) return fail(MCBS_EINVAL, "env %u node %u: bad privilege / countdown", e, n);
+            if (sn[n].discovered) mk[M_DISC][k] |= bit;
+            if (sn[n].installed) mk[M_INST][k] |= bit;
+            if (sn[n].ever_owned) mk[M_EVER][k] |= bit;
+            if (sn[n].running) mk[M_RUN][k] |= bit;
+            if (sn[n].privilege & 1) mk[M_PLO][k] |= bit;
+            if (sn[n].privilege & 2) mk[M_PHI][k] |= bit;
+            owned += sn[n].privilege >= 1;
+            if (!sn[n].running && ring) ring[((size_t)((dclk + sn[n].countdown) & 15u) * S.WT + (n >> 6)) * S.E + e] |= bit;
+            Row r{};
+            r.props_tags = (sn[n].discovered_props & ROW_PROPS_MASK) | ((uint64_t)(sn[n].tags & 0xFu) << 60);
+            r.ever = sn[n].attacked_ever; r.since = sn[n].attacked_since;
+            memcpy(eb + S.off_rows + sizeof(Row) * n, &r, sizeof(r));
+        }
+        for (uint32_t i = 0; i < sh->n_discovered; ++i) {
+            if (order[i] >= S.N) return fail(MCBS_EINVAL, "env %u: discovery order entry out of range", e);
+            eb[S.off_disc + i] = (uint8_t)order[i];
+        }
+        uint16_t* cl = reinterpret_cast<uint16_t*>(eb + S.off_cred);
+        for (uint32_t i = 0; i < sh->n_creds; ++i) {
+            if (cc[i] >= th->n_triples) return fail(MCBS_EINVAL, "env %u: credential cache entry out of range", e);
+            cl[i] = cc[i];
+            mk[M_CACH][(size_t)(cc[i] >> 6) * S.E + e] |= 1ull << (cc[i] & 63u);
+            const uint32_t c = tr[cc[i]].cred;                     // a cached triple implies its credential string is gathered
+            mk[M_GATH][(size_t)(c >> 6) * S.E + e] |= 1ull << (c & 63u);
+        }
+        const uint32_t flags = (sh->done ? F_DONE : 0u) | (sh->truncated ? F_TRUNC : 0u) | (sh->last_oob ? F_OOB : 0u) |
+                               ((sh->last_outcome_kind & 0xFu) << F_KIND_SHIFT) | ((sh->last_escalation & 3u) << F_LEVEL_SHIFT) |
+                               ((sh->last_new_nodes & 0x3FFu) << F_NEWNODES_SHIFT) | ((sh->last_new_creds & 0x3FFu) << F_NEWCREDS_SHIFT);
+        h0[e] = make_uint4(sh->step_count, flags, sh->n_discovered | (sh->n_creds << 16), owned | (dclk << 16));
+        h1[e] = make_double2(sh->cum_reward, sh->availability);
+        ep[e] = sh->episode;
+    }
+    HIP_TRY(hipMemcpy(b->arena, host.data(), b->arena_bytes, hipMemcpyHostToDevice));
+    return MCBS_OK;
 }
 
 // diagnostic builds (-DMCBS_DIAG): per-wavefront s_memtime stamps of the next step launches; not part of the public ABI

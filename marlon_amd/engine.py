@@ -259,6 +259,19 @@ class BatchEngine:
         _check(self.lib, self.lib.mcbs_get_state(self._h, buf.ctypes.data, buf.size), "mcbs_get_state")
         return split_state(buf, self.E, self.topo.n_nodes, self.spec.maximum_total_credentials)
 
+    def set_state(self, hdr, nodes, order, cache) -> None:
+        """Inverse of get_state (parity / debugging): upload canonical state records."""
+        from ._abi import STATE_HEADER_DT, STATE_NODE_DT
+        N, Cm = self.topo.n_nodes, self.spec.maximum_total_credentials
+        rb = state_record_bytes(N, Cm)
+        raw = np.zeros((self.E, rb), np.uint8)
+        raw[:, :64] = np.ascontiguousarray(hdr.astype(STATE_HEADER_DT)).view(np.uint8).reshape(self.E, 64)
+        raw[:, 64:64 + 32 * N] = np.ascontiguousarray(nodes.astype(STATE_NODE_DT)).view(np.uint8).reshape(self.E, 32 * N)
+        o = 64 + 32 * N
+        raw[:, o:o + 2 * N] = np.ascontiguousarray(order.astype("<u2")).view(np.uint8).reshape(self.E, 2 * N)
+        raw[:, o + 2 * N:o + 2 * N + 2 * Cm] = np.ascontiguousarray(cache.astype("<u2")).view(np.uint8).reshape(self.E, 2 * Cm)
+        _check(self.lib, self.lib.mcbs_set_state(self._h, raw.ctypes.data, raw.size), "mcbs_set_state")
+
     def timing_enable(self, on: bool = True) -> None:
         _check(self.lib, self.lib.mcbs_timing_enable(self._h, int(on)), "mcbs_timing_enable")
 

@@ -173,3 +173,34 @@ def test_full_size_properties_chain10_65536():
     assert (nodes["privilege"][nodes["installed"] == 1] >= 1).all()
     assert (hdr["n_creds"] <= 11).all() and (hdr["step_count"] <= 100).all()
     assert tot.sum() > 0
+
+
+def test_set_state_round_trip_and_continuation():
+    """mcbs_set_state(mcbs_get_state()) is the identity, and a batch loaded from another batch's state continues
+    exactly like it (ToyCtf + defender, nodes mid re-imaging included)."""
+    from marlon_amd._abi import RNG_PHILOX
+    _, sj = parity.load_trace("toyctf_marlon_s14")
+    topo = parity.topology_for("toyctf")
+    E = 1024
+    spec = parity.spec_from_json(sj, n_envs=E, auto_reset=True, rng_kind=RNG_PHILOX, seed=21)
+    a = _engine().BatchEngine(topo, spec)
+    for t in range(90):
+        a.step(a.sample_actions(True, seed=5, step=t))
+    st = a.get_state()
+    assert (st[1]["running"] == 0).any()                      # some nodes are being re-imaged at this point
+    spec_b = parity.spec_from_json(sj, n_envs=E, auto_reset=True, rng_kind=RNG_PHILOX, seed=21)
+    b = _engine().BatchEngine(topo, spec_b)
+    b.set_state(*st)
+    _compare_states(b.get_state(), st, "round trip")
+    a.set_state(*st)
+    _compare_states(a.get_state(), st, "identity")
+    for t in range(90, 150):
+        act = a.sample_actions(True, seed=5, step=t)
+        ra, da = a.step(act)
+        rb, db = b.step(act)
+        np.testing.assert_array_equal(ra.cpu().numpy(), rb.cpu().numpy(), err_msg=f"step {t} reward")
+        np.testing.assert_array_equal(da.cpu().numpy(), db.cpu().numpy(), err_msg=f"step {t} done")
+        np.testing.assert_array_equal(a.info["network_availability"].cpu().numpy(), b.info["network_availability"].cpu().numpy())
+    _compare_states(a.get_state(), b.get_state(), "continuation")
+    a.close()
+    b.close()
