@@ -102,7 +102,20 @@ typedef struct mcbs_topo_header { /* 192 bytes */
     uint32_t off_init_order;      /* uint8[n_nodes]: nodes owned at reset, network order, then 0xFF */
     uint32_t n_init_owned;
     double   full_sum;            /* node-order sum of every avail_term (numerator of full_availability) */
-    uint32_t reserved[12];
+    /* learned-defender tier (marlon/defender_agents/defender.py): firewall rule lists by NAME */
+    /* Rule LISTS are first-class: topologies routinely hand the same Python list object to several nodes / directions
+     * (toy_ctf.py:14-19,25,73; chainpattern.py:49-54,103), copy.deepcopy keeps that aliasing inside each env, so an edit
+     * through one node is seen through every alias.  A node refers to its two lists by id. */
+    uint32_t off_fw_rule;         /* mcbs_fw_rule[n_fw_rules]: the rules of list 0, then list 1, ... in list order (oracle) */
+    uint32_t n_fw_rules;
+    uint32_t off_fw_range;        /* uint16[n_fw_lists * 2]: {offset, count} of each list in the rule array */
+    uint32_t n_names;             /* firewall port names: ids 0..n_ports-1 are the identifier ports, then other names */
+    uint8_t  rule_name[8];        /* name ids of LearningDefender.firewall_rule_list = RDP, SSH, HTTPS, HTTP, su, sudo (6 used) */
+    uint8_t  rule_port[8];        /* identifier-port index of each of those names, 0xFF if it is not an identifier port */
+    uint32_t n_fw_lists;          /* distinct rule list objects */
+    uint32_t off_fw_list0;        /* uint16[n_fw_lists]: initial state of the six manageable names in each list: bit r = a rule named r
+                                     exists, bit 6+r = the first one is ALLOW */
+    uint32_t reserved[2];
 } mcbs_topo_header;
 
 typedef struct mcbs_node_static { /* 64 bytes */
@@ -119,8 +132,14 @@ typedef struct mcbs_node_static { /* 64 bytes */
     uint8_t  priv0;        /* initial privilege level */
     uint8_t  tags0;        /* privilege_k tags literally present in the initial property list */
     uint8_t  n_slots;
-    uint32_t pad[3];
+    uint32_t fw_lists;     /* rule list ids: incoming | outgoing << 16 (learned-defender tier) */
+    uint32_t pad[2];
 } mcbs_node_static;
+
+typedef struct mcbs_fw_rule { /* 2 bytes */
+    uint8_t name;          /* firewall port name id */
+    uint8_t allow;         /* RulePermission.ALLOW */
+} mcbs_fw_rule;
 
 typedef struct mcbs_vuln_slot { /* 32 bytes; slot s of node n applies to target n */
     double   cost;
@@ -159,6 +178,8 @@ typedef struct mcbs_triple { /* 8 bytes */
  * ================================================================================ */
 #define MCBS_DEFENDER_NONE 0
 #define MCBS_DEFENDER_SCAN_AND_REIMAGE 1 /* ScanAndReimageCompromisedMachines */
+#define MCBS_DEFENDER_EXTERNAL 2         /* no in-env defender; a learned defender acts through mcbs_defender_step
+                                           (marlon: DefenderEnvWrapper + LearningDefender) */
 
 #define MCBS_RNG_PHILOX 0 /* draw i of a step = half (i&1) of Philox4x32-10(key = (seed lo, seed hi ^ env id hi),
                              ctr = (global env id lo, episode, step_count, i>>1)), 53-bit doubles (hi>>5, lo>>6) */
@@ -294,6 +315,30 @@ int  mcbs_sample_actions(mcbs_batch*, int32_t valid, uint64_t seed, uint64_t ste
  * count is turned into a skip row and flagged in invalid[E] (attack_wrapper.py:236-253,286-308). */
 int  mcbs_decode_attacker_actions(mcbs_batch*, const int64_t* multidiscrete, const int64_t* discrete,
                                   int32_t* actions_out, uint8_t* invalid_out, void* stream);
+
+/* ---- learned defender: marlon/baseline_models/env_wrappers/defend_wrapper.py:197-327,329-412,492-534
+ * and marlon/defender_agents/defender.py:31-107, for batches created with MCBS_DEFENDER_EXTERNAL ---- */
+typedef struct mcbs_defender_obs {   /* DefenderEnvWrapper.observe: four MultiBinary fields, int8, network node order */
+    int8_t* infected_nodes;            /* [E, n_nodes]      agent_installed */
+    int8_t* incoming_firewall_status;  /* [E, n_nodes * 6]  a rule named RDP/SSH/HTTPS/HTTP/su/sudo exists in the incoming list */
+    int8_t* outgoing_firewall_status;  /* [E, n_nodes * 6] */
+    int8_t* services_status;           /* [E, n_services]   service.running, node order then service order */
+} mcbs_defender_obs;
+
+/* One defender turn for every env: validity of the action (is_defender_action_valid), then
+ * LearningDefender.executeAction = DefenderAgentActions.on_attacker_step_taken() followed by the action if it was valid.
+ * actions: device int64 [E,12] = DefenderEnvWrapper's MultiDiscrete [5,N,N,6,2,N,6,2,N,3,N,3]:
+ *   [0] kind: 0 reimage([1]) 1 block_traffic([2] node,[3] rule name,[4] incoming) 2 allow_traffic([5],[6],[7])
+ *       3 stop_service([8],[9]) 4 start_service([10],[11]); kind -1 = the empty action (the defender skips its turn, the
+ *       tick still happens); kind <= -2 = the env takes no part in this call (no tick, state untouched).
+ * Outputs (device): valid[E], availability[E] (after the tick), evicted[E] (= __defender_goal_reached), obs (may be NULL).
+ * Reference defects reproduced as they are: stop/start_service never match a service (defender.py:45-48 hands a
+ * ListeningService object to actions.py:782-794) so they change nothing; allow_traffic appends to the INCOMING list in
+ * both branches (defender.py:68).  Not reproduced (DESIGN.md "Q14"): the reference's defender keeps acting on the
+ * environment object that existed before the first reset(); here it always acts on the live environment. */
+int  mcbs_defender_step(mcbs_batch*, const int64_t* actions, uint8_t* valid, double* availability, uint8_t* evicted,
+                        const mcbs_defender_obs* obs, void* stream);
+int  mcbs_defender_observe(mcbs_batch*, const mcbs_defender_obs* obs, void* stream);
 
 /* Defender draw tape for MCBS_RNG_TAPE: device double [E, draws_per_step] consumed by the next
  * step (scan draws first, then detection draws in consumption order). */

@@ -8,7 +8,7 @@ from typing import Optional
 import numpy as np
 
 ABI_VERSION = 1
-DEFENDER_NONE, DEFENDER_SCAN_AND_REIMAGE = 0, 1
+DEFENDER_NONE, DEFENDER_SCAN_AND_REIMAGE, DEFENDER_EXTERNAL = 0, 1, 2
 RNG_PHILOX, RNG_TAPE = 0, 1
 
 
@@ -34,6 +34,10 @@ class ObsBuffers(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "scalars", "leaked_credentials", "credential_cache_matrix", "discovered_nodes_properties",
         "nodes_privilegelevel", "mask_local", "mask_remote", "mask_connect", "mask_discrete")]
+
+
+class DefenderObs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("infected_nodes", "incoming_firewall_status", "outgoing_firewall_status", "services_status")]
 
 
 class InfoBuffers(C.Structure):
@@ -115,6 +119,10 @@ class EnvSpec:
             c.defender_kind = DEFENDER_NONE
             c.scan_frequency = 1
         else:
+            if self.defender[0] == "external":       # learned defender acting through mcbs_defender_step
+                c.defender_kind = DEFENDER_EXTERNAL
+                c.scan_frequency = 1
+                return self._finish(c)
             kind, p, cap, freq = self.defender
             if kind != "scan_and_reimage":
                 raise ValueError(f"unsupported in-env defender {kind!r}")
@@ -122,6 +130,9 @@ class EnvSpec:
                 raise ValueError("scan_frequency must be positive and scan_capacity non-negative")
             c.defender_kind = DEFENDER_SCAN_AND_REIMAGE
             c.scan_probability, c.scan_capacity, c.scan_frequency = float(p), int(cap), int(freq)
+        return self._finish(c)
+
+    def _finish(self, c: BatchCfg) -> BatchCfg:
         c.auto_reset = int(bool(self.auto_reset))
         c.max_episode_steps = int(self.max_episode_steps)
         c.rng_kind = int(self.rng_kind)

@@ -14,6 +14,7 @@
 #include "mcbs_step.hip"
 #include "mcbs_obs.hip"
 #include "mcbs_aux.hip"
+#include "mcbs_defend.hip"
 
 using namespace mcbs;
 
@@ -33,7 +34,7 @@ static int fail(int code, const char* fmt, ...) {
         if (_e != hipSuccess) return fail(MCBS_EHIP, "%s failed: %s", #expr, hipGetErrorString(_e));      \
     } while (0)
 
-struct HotLayout { uint32_t node, desc, payload, service, allowed, triple, avail, bytes; };
+struct HotLayout { uint32_t node, desc, payload, service, allowed, triple, avail, fwlist, bytes; };
 
 struct mcbs_topology {
     std::vector<uint8_t> host;
@@ -128,6 +129,9 @@ extern "C" int mcbs_topology_create(const void* blob, size_t nbytes, int32_t dev
     for (uint32_t i = 0; i < h->n_triples; ++i)
         if (tr[i].node >= h->n_nodes || tr[i].cred >= h->n_cred_strings || tr[i].port >= h->n_ports)
             return fail(MCBS_EINVAL, "triple %u out of range", i);
+    if ((rc = check_section(h, h->off_fw_list0, 2u * (size_t)h->n_fw_lists, "fw_list0"))) return rc;
+    for (uint32_t n = 0; n < h->n_nodes; ++n)
+        if ((ns[n].fw_lists & 0xFFFFu) >= h->n_fw_lists || (ns[n].fw_lists >> 16) >= h->n_fw_lists) return fail(MCBS_EINVAL, "node %u: firewall list id", n);
     const uint8_t* io = b + h->off_init_order;
     if (h->n_init_owned > h->n_nodes) return fail(MCBS_EINVAL, "init order");
     for (uint32_t i = 0; i < h->n_init_owned; ++i) if (io[i] >= h->n_nodes) return fail(MCBS_EINVAL, "init order");
@@ -148,6 +152,7 @@ extern "C" int mcbs_topology_create(const void* blob, size_t nbytes, int32_t dev
         L.allowed = take(sizeof(uint16_t) * h->n_allowed);
         L.triple = take(sizeof(mcbs_triple) * h->n_triples);
         L.avail = take(sizeof(double) * N);
+        L.fwlist = take(sizeof(uint32_t) * N);
         L.bytes = off;
         t->hot_host.assign(off, 0);
         uint8_t* hb = t->hot_host.data();
@@ -157,6 +162,7 @@ extern "C" int mcbs_topology_create(const void* blob, size_t nbytes, int32_t dev
             hn.listen = ns[n].listen; hn.svc_off = ns[n].svc_off; hn.svc_cnt = ns[n].svc_cnt; hn.flags = ns[n].flags;
             memcpy(hb + L.node + sizeof(HotNode) * n, &hn, sizeof(hn));
             memcpy(hb + L.avail + sizeof(double) * n, &ns[n].avail_term, sizeof(double));
+            memcpy(hb + L.fwlist + sizeof(uint32_t) * n, &ns[n].fw_lists, sizeof(uint32_t));
             for (uint32_t c = 0; c < W; ++c) {
                 HotDesc d{};
                 const uint8_t s = so[(size_t)n * W + c];
@@ -217,7 +223,7 @@ extern "C" int mcbs_batch_create(const mcbs_topology* topo, const mcbs_batch_cfg
         return fail(MCBS_ELIMIT, "the topology can leak %u distinct credentials but maximum_total_credentials is %u "
                     "(the reference would overflow its observation space)", h->n_triples, cfg->maximum_total_credentials);
     if (cfg->maximum_discoverable_credentials_per_action > 1023u) return fail(MCBS_ELIMIT, "maximum_discoverable_credentials_per_action too large");
-    if (cfg->defender_kind > MCBS_DEFENDER_SCAN_AND_REIMAGE) return fail(MCBS_EINVAL, "unknown defender kind");
+    if (cfg->defender_kind > MCBS_DEFENDER_EXTERNAL) return fail(MCBS_EINVAL, "unknown defender kind");
     if (cfg->defender_kind == MCBS_DEFENDER_SCAN_AND_REIMAGE && cfg->scan_frequency == 0) return fail(MCBS_EINVAL, "scan_frequency must be positive");
     if (cfg->rng_kind > MCBS_RNG_TAPE) return fail(MCBS_EINVAL, "unknown rng kind");
     if (h->n_cred_strings > 256u || h->n_triples > 256u)
@@ -237,7 +243,9 @@ extern "C" int mcbs_batch_create(const mcbs_topology* topo, const mcbs_batch_cfg
     S.off_disc = 0;                                                             // u8 discovery order, >= 16 bytes
     S.off_cred = (uint32_t)align_up((size_t)N, 16);                             // u16 credential cache, >= 32 bytes
     S.off_rows = (uint32_t)align_up((size_t)S.off_cred + (2u * h->n_triples > 32u ? 2u * h->n_triples : 32u), 16);
-    S.body_stride = (uint32_t)align_up((size_t)S.off_rows + sizeof(Row) * N, 64);
+    const bool external = cfg->defender_kind == MCBS_DEFENDER_EXTERNAL;
+    S.off_fw = external ? (uint32_t)align_up((size_t)S.off_rows + sizeof(Row) * N, 16) : 0u;
+    S.body_stride = (uint32_t)align_up(external ? (size_t)S.off_fw + 2u * h->n_fw_lists : (size_t)S.off_rows + sizeof(Row) * N, 64);
 
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
@@ -246,7 +254,7 @@ extern "C" int mcbs_batch_create(const mcbs_topology* topo, const mcbs_batch_cfg
     if (S.TW > wt) wt = S.TW;
     S.WT = wt <= 1 ? 1 : (wt == 2 ? 2 : 4);
     const size_t o_masks = take(8ull * M_COUNT * S.WT * E);
-    const bool has_def = cfg->defender_kind != MCBS_DEFENDER_NONE;
+    const bool has_def = cfg->defender_kind != MCBS_DEFENDER_NONE;   // in-env or external: both re-image nodes
     const size_t o_ring = has_def ? take(8ull * 16 * S.WT * E) : 0;
     const size_t o_init = take(S.body_stride);
     const size_t o_digest = take(sizeof(ObsDigest) * (size_t)E);
@@ -277,6 +285,7 @@ extern "C" int mcbs_batch_create(const mcbs_topology* topo, const mcbs_batch_cfg
         memcpy(init.data() + S.off_rows + sizeof(Row) * n, &r, sizeof(r));
     }
     memcpy(init.data() + S.off_disc, topo->host.data() + h->off_init_order, h->n_init_owned);
+    if (external) memcpy(init.data() + S.off_fw, topo->host.data() + h->off_fw_list0, 2u * h->n_fw_lists);
     e = hipMemcpy(a + o_init, init.data(), init.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(b->arena); delete b; return fail(MCBS_EHIP, "init image upload failed: %s", hipGetErrorString(e)); }
 
@@ -296,6 +305,7 @@ extern "C" int mcbs_batch_create(const mcbs_topology* topo, const mcbs_batch_cfg
     C.off_node = h->off_node; C.off_slot_of = h->off_slot_of; C.off_slot = h->off_slot; C.off_payload = h->off_payload;
     C.off_service = h->off_service; C.off_allowed = h->off_allowed; C.off_triple = h->off_triple;
     C.hot_node = topo->hot.node; C.hot_desc = topo->hot.desc; C.hot_payload = topo->hot.payload; C.hot_service = topo->hot.service;
+    memcpy(C.rule_port, h->rule_port, 8); C.n_services = h->n_services; C.n_fw_lists = h->n_fw_lists; C.hot_fwlist = topo->hot.fwlist;
     C.hot_allowed = topo->hot.allowed; C.hot_triple = topo->hot.triple; C.hot_avail = topo->hot.avail; C.hot_bytes = topo->hot.bytes;
 
     e = hipMalloc(&b->C_dev, sizeof(StepCfg));
@@ -368,7 +378,7 @@ static int timing_end(mcbs_batch* b, hipStream_t st, size_t slot) {
 
 // Kernel variant: words per set kept in registers (1, 2 or 4), whether the topology tables fit the LDS budget, and
 // whether an in-env defender is configured (its code and loads are compiled out otherwise).
-template <int PHASE, int WT, bool DEF>
+template <int PHASE, int WT, int DEF>
 static void launch_step_v(mcbs_batch* b, const StepIO& io, hipStream_t st) {
     const uint32_t E = b->S.E, lds = b->C.hot_bytes;
     if (lds <= 60000u && !getenv("MCBS_NO_LDS_TOPO")) {
@@ -381,8 +391,9 @@ static void launch_step_v(mcbs_batch* b, const StepIO& io, hipStream_t st) {
 
 template <int PHASE, int WT>
 static void launch_step_nw(mcbs_batch* b, const StepIO& io, hipStream_t st) {
-    if (b->cfg.defender_kind != MCBS_DEFENDER_NONE) launch_step_v<PHASE, WT, true>(b, io, st);
-    else launch_step_v<PHASE, WT, false>(b, io, st);
+    if (b->cfg.defender_kind == MCBS_DEFENDER_SCAN_AND_REIMAGE) launch_step_v<PHASE, WT, MCBS_DEFENDER_SCAN_AND_REIMAGE>(b, io, st);
+    else if (b->cfg.defender_kind == MCBS_DEFENDER_EXTERNAL) launch_step_v<PHASE, WT, MCBS_DEFENDER_EXTERNAL>(b, io, st);
+    else launch_step_v<PHASE, WT, MCBS_DEFENDER_NONE>(b, io, st);
 }
 
 template <int PHASE>
@@ -526,6 +537,34 @@ extern "C" int mcbs_decode_attacker_actions(mcbs_batch* b, const int64_t* multid
     hipLaunchKernelGGL(decode_kernel, dim3((b->S.E + 255) / 256), dim3(256), 0, (hipStream_t)stream, b->S, b->C,
                        b->cfg.maximum_node_count, b->cfg.maximum_total_credentials, multidiscrete, discrete, actions_out, invalid_out);
     return launch_ok("decode");
+}
+
+// ------------------------------------------------------------------ learned defender
+static int launch_defender_obs(mcbs_batch* b, const mcbs_defender_obs* o, hipStream_t st) {
+    const uint32_t total = b->S.E * b->S.N;
+    hipLaunchKernelGGL(defender_obs_kernel, dim3((total + 255) / 256), dim3(256), 0, st, b->S, b->T, o->infected_nodes,
+                       o->incoming_firewall_status, o->outgoing_firewall_status, o->services_status, b->C.n_services);
+    return launch_ok("defender observation");
+}
+
+extern "C" int mcbs_defender_step(mcbs_batch* b, const int64_t* actions, uint8_t* valid, double* availability, uint8_t* evicted,
+                                  const mcbs_defender_obs* obs, void* stream) {
+    if (!b || !actions) return fail(MCBS_EINVAL, "null argument");
+    if (b->cfg.defender_kind != MCBS_DEFENDER_EXTERNAL) return fail(MCBS_ESTATE, "batch was not created with MCBS_DEFENDER_EXTERNAL");
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((b->S.E + 127) / 128), block(128);
+    if (b->S.WT == 1) hipLaunchKernelGGL((defender_kernel<1>), grid, block, 0, st, b->S, b->T, b->C_dev, actions, valid, availability, evicted);
+    else if (b->S.WT == 2) hipLaunchKernelGGL((defender_kernel<2>), grid, block, 0, st, b->S, b->T, b->C_dev, actions, valid, availability, evicted);
+    else hipLaunchKernelGGL((defender_kernel<4>), grid, block, 0, st, b->S, b->T, b->C_dev, actions, valid, availability, evicted);
+    int rc = launch_ok("defender step");
+    if (rc || !obs) return rc;
+    return launch_defender_obs(b, obs, st);
+}
+
+extern "C" int mcbs_defender_observe(mcbs_batch* b, const mcbs_defender_obs* obs, void* stream) {
+    if (!b || !obs) return fail(MCBS_EINVAL, "null argument");
+    if (b->cfg.defender_kind != MCBS_DEFENDER_EXTERNAL) return fail(MCBS_ESTATE, "batch was not created with MCBS_DEFENDER_EXTERNAL");
+    return launch_defender_obs(b, obs, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------ state export / import (debug, synchronous)

@@ -72,6 +72,8 @@ struct DevState {
     const uint8_t* init_body; // [body_stride] image of a freshly reset env
     uint32_t E, N, NW, SW, TW, WT;  // WT = words per set = max(NW, SW, TW) rounded to 1, 2 or 4
     uint32_t body_stride, off_disc, off_cred, off_rows, Cmax;
+    uint32_t off_fw;    // body offset of uint16 fw[n_fw_lists]: per-env state of the six manageable rule names in every firewall
+                        // rule list (bit r: a rule named r exists, bit 6+r: the first one is ALLOW); MCBS_DEFENDER_EXTERNAL only
 };
 
 struct Topo {           // device view of the MCBT blob and of the hot image built from it
@@ -92,6 +94,9 @@ struct StepCfg {        // the parts of mcbs_batch_cfg the kernels read
     uint32_t off_node, off_slot_of, off_slot, off_payload, off_service, off_allowed, off_triple;
     // hot image (Topo::hot) section offsets and size
     uint32_t hot_node, hot_desc, hot_payload, hot_service, hot_allowed, hot_triple, hot_avail, hot_bytes;
+    uint8_t  rule_port[8];   // identifier-port index of RDP, SSH, HTTPS, HTTP, su, sudo (0xFF: not an identifier port)
+    uint32_t n_services, n_fw_lists;
+    uint32_t hot_fwlist;     // uint32[N]: incoming list id | outgoing list id << 16
 };
 
 struct StepIO {

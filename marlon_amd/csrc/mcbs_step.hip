@@ -85,6 +85,9 @@ struct Lane {
     uint64_t props;      // discovered properties (60 bits)
     uint32_t ever, since, tags;
     bool row_dirty;
+    // learned-defender tier: this env's firewall state of source / target (12 bits per rule list, see mcbs_defend.hip), else unused
+    bool learned;
+    uint32_t fw_src, fw_tgt;
     // result of the attacker's action
     double raw;
     int okind, olevel, new_nodes, new_creds;
@@ -124,7 +127,16 @@ struct Lane {
         if (kind == 2) {
             // target is discovered and the credential gathered by construction (both come from this env's own lists)
             const uint32_t cred = (reinterpret_cast<const mcbs_triple*>(tb + C.hot_triple) + triple)->cred;
-            const bool fw_ok = ((NS(src)->fw_out_allow >> port) & 1u) && ((t->fw_in_allow >> port) & 1u);  // BLOCKED_BY_LOCAL/REMOTE_FIREWALL
+            bool out_ok = (NS(src)->fw_out_allow >> port) & 1u, in_ok = (t->fw_in_allow >> port) & 1u;
+            if (learned) {                                   // a manageable rule name: the env's own rule state decides
+#pragma unroll
+                for (uint32_t r = 0; r < 6u; ++r)
+                    if (C.rule_port[r] == port) {
+                        out_ok = ((fw_src >> r) & (fw_src >> (6u + r)) & 1u) != 0;   // fw_src: the source's OUTGOING list
+                        in_ok = ((fw_tgt >> r) & (fw_tgt >> (6u + r)) & 1u) != 0;    // fw_tgt: the target's INCOMING list
+                    }
+            }
+            const bool fw_ok = out_ok && in_ok;                                                           // BLOCKED_BY_LOCAL/REMOTE_FIREWALL
             const bool listening = (t->listen >> port) & 1u;                                              // SCANNING_UNOPEN_PORT
             bool authorized = false;                                                                      // actions.py:608-621
             const mcbs_service* sv = reinterpret_cast<const mcbs_service*>(tb + C.hot_service) + t->svc_off;
@@ -267,20 +279,27 @@ struct Lane {
             const double d = draw(C.scan_capacity + det, step, episode, io);
             det += 1;
             if (!(d <= C.scan_probability) || !(NS((uint32_t)n)->flags & MCBS_NODE_REIMAGABLE)) continue;
-            row((uint32_t)n)->since = 0;                          // every earlier attack now predates last_reimaging
-            rclear<WT>(m[M_INST], (uint32_t)n);
-            if (privilege((uint32_t)n)) { set_privilege((uint32_t)n, 0u); owned -= 1; }   // privilege NoAccess; tags stay
-            rclear<WT>(m[M_RUN], (uint32_t)n);
-            rset<WT>(fresh, (uint32_t)n);
-            dirty |= (1u << M_INST) | (1u << M_RUN);
+            reimage((uint32_t)n, fresh);
         }
+    }
+
+    // reimage_node (actions.py:700-712): agent removed, privilege NoAccess, Imaging for REIMAGING_DURATION ticks; tags,
+    // discovered properties and credentials stay (quirk Q6)
+    __device__ __forceinline__ void reimage(uint32_t n, uint64_t (&fresh)[WT]) {
+        row(n)->since = 0;                                    // every earlier attack now predates last_reimaging
+        rclear<WT>(m[M_INST], n);
+        if (privilege(n)) { set_privilege(n, 0u); owned -= 1; }
+        rclear<WT>(m[M_RUN], n);
+        rset<WT>(fresh, n);
+        dirty |= (1u << M_INST) | (1u << M_RUN);
     }
 };
 
 // PHASE 0: whole step.  PHASE 1: attacker's action only (raw reward parked in S.pending).
 // PHASE 2: defender, goals, outputs, auto-reset (after the observation kernels ran).
 // WT: words per set held in registers (1, 2 or 4; >= NW, SW, TW).  TOPO_LDS: topology tables staged in LDS.
-template <int PHASE, int WT, bool TOPO_LDS, bool DEF>
+// DEFK: MCBS_DEFENDER_* (none / in-env ScanAndReimage / external learned defender).
+template <int PHASE, int WT, bool TOPO_LDS, int DEFK>
 __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, const StepCfg* __restrict__ Cp, StepIO io) {
     const StepCfg& C = *Cp;   // in device memory: fields are fetched by scalar loads where they are used, not all up front
     extern __shared__ uint4 topo_lds[];
@@ -296,7 +315,8 @@ __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, const Ste
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = e < S.E;
     const uint32_t ec = active ? e : 0u;                // clamp so inactive lanes read valid memory and take no branch
-    constexpr bool has_def = DEF;   // C.defender_kind != MCBS_DEFENDER_NONE, resolved at launch
+    constexpr bool has_def = DEFK == MCBS_DEFENDER_SCAN_AND_REIMAGE;   // in-env defender, resolved at launch
+    constexpr bool learned = DEFK == MCBS_DEFENDER_EXTERNAL;           // firewall rules are per-env state (learned defender)
 
     // ---------------- level 1: loads whose addresses depend on the env index only ----------------
     uint8_t* body = S.body + (size_t)ec * S.body_stride;
@@ -357,7 +377,7 @@ __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, const Ste
             if (io.raw_reward) io.raw_reward[e] = 0.0f;
         }
     } else if (active) {
-        Lane<WT> ln{S, C, tb, e, body, h0.z & 0xFFFFu, h0.z >> 16, h0.w & 0xFFFFu, h0.w >> 16, {}, 0u, 0ull, 0u, 0u, 0u, false,
+        Lane<WT> ln{S, C, tb, e, body, h0.z & 0xFFFFu, h0.z >> 16, h0.w & 0xFFFFu, h0.w >> 16, {}, 0u, 0ull, 0u, 0u, 0u, false, learned, 0u, 0u,
                     0.0, MCBS_OUT_NONE, 0, 0, 0};
 #pragma unroll
         for (int k = 0; k < M_COUNT; ++k)
@@ -395,6 +415,11 @@ __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, const Ste
                 const uint64_t pt = (uint64_t)r0.x | ((uint64_t)r0.y << 32);
                 ln.props = pt & ROW_PROPS_MASK; ln.tags = (uint32_t)(pt >> 60);
                 ln.ever = r0.z; ln.since = r0.w;
+                if (learned && kind == 2) {
+                    const uint16_t* fw = reinterpret_cast<const uint16_t*>(body + S.off_fw);
+                    const uint32_t* lists = reinterpret_cast<const uint32_t*>(tb + C.hot_fwlist);
+                    ln.fw_src = fw[lists[src] >> 16]; ln.fw_tgt = fw[lists[tgt] & 0xFFFFu];
+                }
                 STAMP(3);  // row landed
                 uint32_t triple = 0;
                 if (kind == 2) {

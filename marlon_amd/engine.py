@@ -13,7 +13,7 @@ from typing import Dict, Iterable, Optional
 
 import numpy as np
 
-from ._abi import BatchCfg, EnvSpec, InfoBuffers, ObsBuffers, split_state, state_record_bytes
+from ._abi import BatchCfg, DefenderObs, EnvSpec, InfoBuffers, ObsBuffers, split_state, state_record_bytes
 from .flatten import FlatTopology
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -22,7 +22,7 @@ LIB_PATH = os.path.join(_HERE, "libmcbs.so")
 EXPORTS = [
     "mcbs_last_error", "mcbs_abi_version", "mcbs_topology_create", "mcbs_topology_destroy", "mcbs_batch_create",
     "mcbs_batch_destroy", "mcbs_reset", "mcbs_step", "mcbs_step_observe", "mcbs_observe", "mcbs_observe_masked", "mcbs_action_mask", "mcbs_step_info",
-    "mcbs_sample_actions", "mcbs_decode_attacker_actions", "mcbs_set_draw_tape", "mcbs_state_record_bytes", "mcbs_get_state", "mcbs_set_state",
+    "mcbs_sample_actions", "mcbs_decode_attacker_actions", "mcbs_defender_step", "mcbs_defender_observe", "mcbs_set_draw_tape", "mcbs_state_record_bytes", "mcbs_get_state", "mcbs_set_state",
     "mcbs_timing_enable", "mcbs_timing_read",
 ]
 
@@ -64,6 +64,8 @@ def load_library(path: Optional[str] = None):
     lib.mcbs_step_info.argtypes = [C.c_void_p, C.POINTER(InfoBuffers), C.c_void_p]
     lib.mcbs_sample_actions.argtypes = [C.c_void_p, C.c_int32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
     lib.mcbs_decode_attacker_actions.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.mcbs_defender_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(DefenderObs), C.c_void_p]
+    lib.mcbs_defender_observe.argtypes = [C.c_void_p, C.POINTER(DefenderObs), C.c_void_p]
     lib.mcbs_set_draw_tape.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
     lib.mcbs_state_record_bytes.restype = C.c_size_t
     lib.mcbs_state_record_bytes.argtypes = [C.c_void_p]
@@ -251,6 +253,34 @@ class BatchEngine:
             self._h, src.data_ptr() if multidiscrete is not None else None, src.data_ptr() if discrete is not None else None,
             actions_out.data_ptr(), invalid_out.data_ptr(), self._stream()), "mcbs_decode_attacker_actions")
         return actions_out, invalid_out
+
+    # -- learned defender (batches created with defender=("external",)) --
+    def alloc_defender_obs(self) -> dict:
+        t, N, S = self.torch, self.topo.n_nodes, int(self.topo.header()["n_services"])
+        mk = lambda n: t.zeros((self.E, n), dtype=t.int8, device=self.device)
+        return dict(infected_nodes=mk(N), incoming_firewall_status=mk(6 * N), outgoing_firewall_status=mk(6 * N), services_status=mk(S))
+
+    def defender_step(self, actions12, obs: Optional[dict] = None):
+        """DefenderEnvWrapper's validity check + LearningDefender.executeAction for every env.
+        -> (valid u8 [E], availability f64 [E], evicted u8 [E]) device tensors."""
+        t = self.torch
+        a = actions12 if isinstance(actions12, t.Tensor) else t.as_tensor(np.asarray(actions12))
+        a = a.to(device=self.device, dtype=t.int64).contiguous()
+        if tuple(a.shape) != (self.E, 12):
+            raise ValueError(f"defender actions must have shape ({self.E}, 12), got {tuple(a.shape)}")
+        if not hasattr(self, "_def_out"):
+            self._def_out = (t.zeros(self.E, dtype=t.uint8, device=self.device), t.zeros(self.E, dtype=t.float64, device=self.device),
+                             t.zeros(self.E, dtype=t.uint8, device=self.device))
+        v, av, ev = self._def_out
+        o = DefenderObs(**{k: x.data_ptr() for k, x in obs.items()}) if obs is not None else None
+        _check(self.lib, self.lib.mcbs_defender_step(self._h, a.data_ptr(), v.data_ptr(), av.data_ptr(), ev.data_ptr(),
+                                                     C.byref(o) if o is not None else None, self._stream()), "mcbs_defender_step")
+        return v, av, ev
+
+    def defender_observe(self, obs: dict) -> dict:
+        o = DefenderObs(**{k: x.data_ptr() for k, x in obs.items()})
+        _check(self.lib, self.lib.mcbs_defender_observe(self._h, C.byref(o), self._stream()), "mcbs_defender_observe")
+        return obs
 
     def get_state(self):
         rb = state_record_bytes(self.topo.n_nodes, self.spec.maximum_total_credentials)

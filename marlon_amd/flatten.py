@@ -42,6 +42,7 @@ OUT_NONE, OUT_LEAKED_CREDENTIALS, OUT_LEAKED_NODES, OUT_PRIVILEGE_ESCALATION, OU
     OUT_CUSTOMER_DATA, OUT_PROBE_SUCCEEDED, OUT_PROBE_FAILED, OUT_EXPLOIT_FAILED, OUT_OTHER = range(10)
 
 NODE_INSTALLED0, NODE_REIMAGABLE = 1, 2
+DEFENDER_RULE_NAMES = ("RDP", "SSH", "HTTPS", "HTTP", "su", "sudo")   # LearningDefender.firewall_rule_list (defender.py:24)
 TAG_NAMES = tuple(f"privilege_{k}" for k in range(4))
 
 HEADER_DT = np.dtype([
@@ -53,13 +54,15 @@ HEADER_DT = np.dtype([
     ("total_sla_weight", "<f8"), ("full_availability", "<f8"),
     ("off_node", "<u4"), ("off_slot_of", "<u4"), ("off_slot", "<u4"), ("off_payload", "<u4"),
     ("off_service", "<u4"), ("off_allowed", "<u4"), ("off_triple", "<u4"), ("off_code", "<u4"),
-    ("off_init_order", "<u4"), ("n_init_owned", "<u4"), ("full_sum", "<f8"), ("reserved", "<u4", (12,)),
+    ("off_init_order", "<u4"), ("n_init_owned", "<u4"), ("full_sum", "<f8"),
+    ("off_fw_rule", "<u4"), ("n_fw_rules", "<u4"), ("off_fw_range", "<u4"), ("n_names", "<u4"),
+    ("rule_name", "u1", (8,)), ("rule_port", "u1", (8,)), ("n_fw_lists", "<u4"), ("off_fw_list0", "<u4"), ("reserved", "<u4", (2,)),
 ])
 NODE_DT = np.dtype([
     ("props", "<u8"), ("sla_weight", "<f8"), ("avail_term", "<f8"), ("value", "<i4"),
     ("fw_in_allow", "<u4"), ("fw_out_allow", "<u4"), ("listen", "<u4"), ("local_mask", "<u4"),
     ("svc_off", "<u2"), ("svc_cnt", "<u2"), ("flags", "u1"), ("priv0", "u1"), ("tags0", "u1"), ("n_slots", "u1"),
-    ("pad", "<u4", (3,)),
+    ("fw_lists", "<u4"), ("pad", "<u4", (2,)),
 ])
 SLOT_DT = np.dtype([
     ("cost", "<f8"), ("probe_mask", "<u8"), ("payload_off", "<u4"), ("payload_cnt", "<u2"), ("precond_tt", "<u2"),
@@ -228,6 +231,17 @@ def flatten(environment) -> FlatTopology:
     if V > MAX_SLOTS:
         raise ValueError(f"a node carries {V} vulnerabilities; the engine supports at most {MAX_SLOTS}")
 
+    # firewall port names: identifier ports first (same ids), then every other name a rule or the learned defender uses
+    name_index: Dict[str, int] = dict(port_index)
+    for extra in list(DEFENDER_RULE_NAMES) + [r.port for _, info in nodes for r in list(info.firewall.incoming) + list(info.firewall.outgoing)]:
+        name_index.setdefault(extra, len(name_index))
+    if len(name_index) > 255:
+        raise ValueError("too many distinct firewall port names")
+    fw_rules: List[Tuple[int, int]] = []
+    fw_list_id: Dict[int, int] = {}          # id(list object) -> list index: aliasing between nodes / directions is state
+    fw_range: List[Tuple[int, int]] = []
+    fw_list0: List[int] = []
+
     slot_tab = np.zeros((N, V), SLOT_DT)
     payload: List[Tuple[int, int, int, int]] = []
     services: List[Tuple[float, int, int, int, int]] = []
@@ -246,6 +260,20 @@ def flatten(environment) -> FlatTopology:
         rec["fw_in_allow"] = _first_match_mask(info.firewall.incoming, ports)
         rec["fw_out_allow"] = _first_match_mask(info.firewall.outgoing, ports)
         rec["listen"] = sum(1 << port_index[s] for s in {s.name for s in info.services})
+        ids_of = []
+        for rules in (info.firewall.incoming, info.firewall.outgoing):
+            if id(rules) not in fw_list_id:
+                fw_list_id[id(rules)] = len(fw_range)
+                fw_range.append((len(fw_rules), len(rules)))
+                fw_rules.extend((name_index[r.port], int(_is_allow(r))) for r in rules)
+                bits = 0
+                for k, name in enumerate(DEFENDER_RULE_NAMES):
+                    first = next((r for r in rules if r.port == name), None)
+                    if first is not None:
+                        bits |= (1 << k) | ((1 << (6 + k)) if _is_allow(first) else 0)
+                fw_list0.append(bits)
+            ids_of.append(fw_list_id[id(rules)])
+        rec["fw_lists"] = ids_of[0] | (ids_of[1] << 16)
         rec["local_mask"] = sum(1 << l for l, vid in enumerate(local_ids) if vid in library or vid in info.vulnerabilities)
         installed = bool(info.agent_installed)
         priv0 = int(info.privilege_level)
@@ -360,6 +388,8 @@ def flatten(environment) -> FlatTopology:
         ("payload", payload_tab.tobytes()), ("service", service_tab.tobytes()),
         ("allowed", np.array(allowed, np.uint16).tobytes()), ("triple", triple_tab.tobytes()),
         ("code", bytes(code)), ("init_order", init_order.tobytes()),
+        ("fw_rule", np.array(fw_rules, np.uint8).reshape(-1, 2).tobytes()), ("fw_range", np.array(fw_range, np.uint16).reshape(-1, 2).tobytes()),
+        ("fw_list0", np.array(fw_list0, np.uint16).tobytes()),
     ]
     hdr = np.zeros(1, HEADER_DT)
     h = hdr[0]
@@ -381,6 +411,10 @@ def flatten(environment) -> FlatTopology:
     h["avail_any_order"] = any_order
     h["total_sla_weight"], h["full_availability"], h["full_sum"] = total_weight, full_avail, float(full)
     h["n_init_owned"] = len(init_owned)
+    h["n_fw_rules"], h["n_names"], h["n_fw_lists"] = len(fw_rules), len(name_index), len(fw_range)
+    h["rule_name"][:6] = [name_index[n] for n in DEFENDER_RULE_NAMES]
+    h["rule_port"][:] = 0xFF
+    h["rule_port"][:6] = [port_index.get(n, 0xFF) for n in DEFENDER_RULE_NAMES]
     blob = hdr.tobytes() + bytes(body)
 
     return FlatTopology(

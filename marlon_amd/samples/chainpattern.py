@@ -47,7 +47,7 @@ def _vuln(kind: m.VulnerabilityType, outcome: m.VulnerabilityOutcome, cost: floa
     return m.VulnerabilityInfo(description=text, type=kind, outcome=outcome, cost=cost, reward_string=why)
 
 
-def _linux_node(n: int) -> m.NodeInfo:
+def _linux_node(n: int, shared_rules) -> m.NodeInfo:
     nxt = prefix(n + 1, "WindowsNode")
     L, R = m.VulnerabilityType.LOCAL, m.VulnerabilityType.REMOTE
     vulns = {
@@ -61,7 +61,9 @@ def _linux_node(n: int) -> m.NodeInfo:
     }
     return m.NodeInfo(
         services=[m.ListeningService("HTTPS"), m.ListeningService("SSH", allowedCredentials=[ssh_password(n)])],
-        firewall=m.FirewallConfiguration(incoming=_allow_all(), outgoing=_allow_all()),
+        # one rule list object serves both directions of every Linux link node, as in the reference (chainpattern.py:49-54,103):
+        # an edit through one node is seen by all of them
+        firewall=m.FirewallConfiguration(incoming=shared_rules, outgoing=shared_rules),
         value=100, properties=list(LINUX_PROPS), vulnerabilities=vulns,
         owned_string="Intermediate chain node owned, no intrinsic value")
 
@@ -85,8 +87,9 @@ def _windows_node(n: int) -> m.NodeInfo:
         value=100, properties=list(WINDOWS_PROPS), vulnerabilities=vulns)
 
 
-def create_network_chain_link(n: int) -> Dict[m.NodeID, m.NodeInfo]:
-    return {prefix(n, "LinuxNode"): _linux_node(n), prefix(n + 1, "WindowsNode"): _windows_node(n)}
+def create_network_chain_link(n: int, shared_rules=None) -> Dict[m.NodeID, m.NodeInfo]:
+    shared_rules = _allow_all() if shared_rules is None else shared_rules
+    return {prefix(n, "LinuxNode"): _linux_node(n, shared_rules), prefix(n + 1, "WindowsNode"): _windows_node(n)}
 
 
 def create_chain_network(size: int) -> Dict[m.NodeID, m.NodeInfo]:
@@ -104,8 +107,9 @@ def create_chain_network(size: int) -> Dict[m.NodeID, m.NodeInfo]:
             value=1000, owned_string="FLAG: flag discovered!",
             properties=LINUX_PROPS + ["FLAG:Linux"], vulnerabilities={}),
     }
+    shared = _allow_all()
     for i in range(1, size, 2):
-        nodes.update(create_network_chain_link(i))
+        nodes.update(create_network_chain_link(i, shared))
     return nodes
 
 

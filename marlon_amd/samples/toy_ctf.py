@@ -85,6 +85,8 @@ def _outcome(spec) -> m.VulnerabilityOutcome:
 
 def _build() -> Dict[m.NodeID, m.NodeInfo]:
     out: Dict[m.NodeID, m.NodeInfo] = {}
+    stock = _rules(STOCK)   # ONE list object wherever the spec says exactly STOCK, as the reference's default_allow_rules
+                            # (toy_ctf.py:14-19: Website incoming and Website[user=monitor] outgoing are the same list)
     for node_id, s in _SPEC:
         vulns = {}
         for vid, (kind, outcome, pre) in s["vulns"].items():
@@ -95,7 +97,8 @@ def _build() -> Dict[m.NodeID, m.NodeInfo]:
             vulns[vid] = m.VulnerabilityInfo(**kw)
         fw = m.FirewallConfiguration()
         if "fw_in" in s:
-            fw = m.FirewallConfiguration(incoming=_rules(s["fw_in"]), outgoing=_rules(s["fw_out"]))
+            fw = m.FirewallConfiguration(incoming=stock if s["fw_in"] is STOCK else _rules(s["fw_in"]),
+                                         outgoing=stock if s["fw_out"] is STOCK else _rules(s["fw_out"]))
         out[node_id] = m.NodeInfo(
             services=[m.ListeningService(p, allowedCredentials=list(c)) for p, c in s["services"]],
             vulnerabilities=vulns, value=s["value"], properties=list(s["props"]), firewall=fw,

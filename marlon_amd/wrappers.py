@@ -39,7 +39,7 @@ class AttackerVecEnv:
                  defender_goal=DefenderGoal(eviction=True), defender_constraint=DefenderConstraint(maintain_sla=0.0),
                  winning_reward=5000.0, losing_reward=0.0, max_timesteps: int = 2000, invalid_action_reward_modifier=-1,
                  discrete: bool = False, auto_reset: bool = True, device: Optional[str] = None, seed: int = 0,
-                 env_id_base: int = 0, rng_kind: int = 0):
+                 env_id_base: int = 0, rng_kind: int = 0, learned_defender: bool = False):
         from .engine import BatchEngine
         self.topo: FlatTopology = initial_environment if isinstance(initial_environment, FlatTopology) else flatten(initial_environment)
         # the wrapper owns truncation and resets (its clock counts invalid actions too), so the engine's own are off
@@ -47,6 +47,10 @@ class AttackerVecEnv:
                                               maximum_discoverable_credentials_per_action, defender_agent, attacker_goal,
                                               defender_goal, defender_constraint, winning_reward, losing_reward,
                                               auto_reset=False, max_episode_steps=0, seed=seed, env_id_base=env_id_base, rng_kind=rng_kind)
+        if learned_defender:
+            if defender_agent is not None:
+                raise ValueError("a learned defender replaces the in-env defender_agent (multiagent_universe.py:160-167)")
+            self.spec.defender = ("external",)
         self.engine = BatchEngine(self.topo, self.spec, device=device)
         t = self.torch = self.engine.torch
         self.num_envs = n_envs
@@ -67,6 +71,8 @@ class AttackerVecEnv:
         self.valid_action_count = t.zeros(n_envs, dtype=t.int64, device=dev)
         self.invalid_action_count = t.zeros(n_envs, dtype=t.int64, device=dev)
         self.episode_returns = t.zeros(n_envs, dtype=t.float64, device=dev)
+        self.last_cyber_reward = t.zeros(n_envs, dtype=t.float32, device=dev)
+        self.has_cyber_reward = t.zeros(n_envs, dtype=t.bool, device=dev)    # AttackerEnvWrapper.cyber_rewards is non-empty
         self.reset()
 
     # -- observation plumbing --
@@ -100,6 +106,7 @@ class AttackerVecEnv:
         self.valid_action_count.zero_()
         self.invalid_action_count.zero_()
         self.episode_returns.zero_()
+        self.has_cyber_reward.zero_()
         return self.observation
 
     def step(self, actions):
@@ -114,11 +121,13 @@ class AttackerVecEnv:
         self.timesteps += 1
         self.invalid_action_count += invalid
         self.valid_action_count += ~invalid
+        self.last_cyber_reward = reward.clone()                                                   # AttackerEnvWrapper.cyber_rewards[-1]
         rewards = reward + invalid.to(reward.dtype) * self.invalid_action_reward_modifier        # attack_wrapper.py:296,354
         truncated = self.timesteps >= self.max_timesteps                                          # :350-352
         terminated = terminated != 0
         dones = terminated | truncated
         self.episode_returns += rewards.double()
+        self.has_cyber_reward |= True
         info = {"invalid_action": invalid, "cyber_step_executed": ~invalid,
                 "network_availability": self.engine.info["network_availability"], "step_count": self.engine.info["step_count"],
                 "episode_return": self.episode_returns.clone(), "episode_length": self.timesteps.clone()}
@@ -133,7 +142,87 @@ class AttackerVecEnv:
             self.valid_action_count *= keep
             self.invalid_action_count *= keep
             self.episode_returns *= keep
+            self.has_cyber_reward &= keep
         return self.observation, rewards, terminated.to(t.uint8), truncated.to(t.uint8), info
 
     def close(self) -> None:
         self.engine.close()
+
+
+class DefenderVecEnv:
+    """`DefenderEnvWrapper` + `LearningDefender` (marlon/baseline_models/env_wrappers/defend_wrapper.py,
+    marlon/defender_agents/defender.py) for the batch an `AttackerVecEnv(..., learned_defender=True)` owns: the two
+    wrappers share one environment batch, as in MultiAgentUniverse.build (multiagent_universe.py:160-199).
+
+    step(actions[E,12]) = validity check + executeAction on the device (`mcbs_defender_step`), then the wrapper's reward
+    shaping (defend_wrapper.py:228-282): invalid-action penalty, minus the attacker's last environment reward, a one-time
+    `loss_reward` when availability first drops below `maintain_sla` (terminating if reset_on_constraint_broken), a
+    worsening penalty while breached, `winning_reward` on eviction; truncation at max_timesteps.
+    The learned defender always acts on the live environment."""
+
+    def __init__(self, attacker: AttackerVecEnv, max_timesteps: int = 100, invalid_action_reward: float = 0.0,
+                 reset_on_constraint_broken: bool = True, loss_reward: float = -5000.0, sla_worsening_penalty_scale: float = 200.0):
+        self.attacker = attacker
+        self.engine = attacker.engine
+        t = self.torch = attacker.torch
+        E, dev = attacker.num_envs, self.engine.device
+        self.num_envs = E
+        self.max_timesteps = int(max_timesteps)
+        self.invalid_action_penalty = float(invalid_action_reward)
+        self.reset_on_constraint_broken = bool(reset_on_constraint_broken)
+        self.loss_reward = float(loss_reward)
+        self.sla_worsening_penalty_scale = float(sla_worsening_penalty_scale)
+        self.maintain_sla = float(attacker.spec.maintain_sla)
+        self.winning_reward = float(attacker.spec.winning_reward)
+        N = attacker.topo.n_nodes
+        self.nvec = np.array([5, N, N, 6, 2, N, 6, 2, N, 3, N, 3], dtype=np.int64)          # defend_wrapper.py:162-195
+        self._obs = self.engine.alloc_defender_obs()
+        self.timesteps = t.zeros(E, dtype=t.int32, device=dev)
+        self.has_breached_sla = t.zeros(E, dtype=t.bool, device=dev)
+        self.prev_availability = t.ones(E, dtype=t.float64, device=dev)
+        self.valid_action_count = t.zeros(E, dtype=t.int64, device=dev)
+        self.invalid_action_count = t.zeros(E, dtype=t.int64, device=dev)
+        self.reset()
+
+    @property
+    def observation(self) -> Dict[str, object]:
+        return self._obs
+
+    def reset(self, env_mask=None):
+        """Wrapper state of the envs in env_mask (all if None); the environment itself is reset by the attacker side."""
+        t = self.torch
+        self.engine.defender_observe(self._obs)
+        avail = self.engine.step_info()["network_availability"]
+        keep = t.zeros(self.num_envs, dtype=t.bool, device=self.engine.device) if env_mask is None else ~(env_mask != 0)
+        self.timesteps *= keep
+        self.valid_action_count *= keep
+        self.invalid_action_count *= keep
+        self.has_breached_sla &= keep
+        self.prev_availability = t.where(keep, self.prev_availability, avail)
+        return self._obs
+
+    def step(self, actions):
+        """-> (observation dict, reward f64 [E], terminated u8 [E], truncated u8 [E], info)."""
+        t = self.torch
+        valid, avail, evicted = self.engine.defender_step(actions, self._obs)
+        valid = valid != 0
+        self.valid_action_count += valid
+        self.invalid_action_count += ~valid
+        reward = (~valid).double() * self.invalid_action_penalty
+        reward = reward - t.where(self.attacker.has_cyber_reward, self.attacker.last_cyber_reward.double(), t.zeros_like(reward))
+        worsening = self.prev_availability - avail
+        breached = avail < self.maintain_sla
+        first = breached & ~self.has_breached_sla
+        reward = reward + first.double() * self.loss_reward
+        again = breached & self.has_breached_sla & (worsening > 0)
+        reward = reward + t.where(again, -self.sla_worsening_penalty_scale * worsening, t.zeros_like(reward))
+        terminated = first if self.reset_on_constraint_broken else t.zeros_like(first)
+        self.has_breached_sla = breached
+        self.prev_availability = avail.clone()
+        won = evicted != 0                                                                   # defender goal: attacker evicted
+        reward = t.where(won, t.full_like(reward, self.winning_reward), reward)
+        terminated = terminated | won
+        self.timesteps += 1
+        truncated = self.timesteps >= self.max_timesteps
+        info = {"valid_action": valid, "network_availability": avail.clone(), "sla_breached": breached, "defender_won": won}
+        return self._obs, reward, terminated.to(t.uint8), truncated.to(t.uint8), info

@@ -65,6 +65,9 @@ typedef struct {
     int* discovered;    int n_discovered;/* CyberBattleEnv.__discovered_nodes */
     int* cache;         int n_cache;     /* CyberBattleEnv.__credential_cache (triple ids) */
     int* gathered;                       /* AgentActions._gathered_credentials, by credential-string id */
+    /* the firewall rule list objects (model.py:275-305), mutable by the learned defender; a node's incoming / outgoing
+     * list is looked up by id because several nodes / directions may hold the SAME list object */
+    mcbs_fw_rule** fwl; int* n_fwl;
     int64_t clock;
     int stepcount, done, truncated, episode;
     double episode_reward_sum;           /* numpy.sum(__episode_rewards): rewards are exact integers or one rounded
@@ -85,6 +88,8 @@ typedef struct {
     const uint16_t* AL;
     const mcbs_triple* TR;
     const uint8_t* CODE;
+    const mcbs_fw_rule* FWR;
+    const uint16_t* FWRANGE;
     mcbs_batch_cfg cfg;
     int n_envs;
     oenv* env;
@@ -262,13 +267,22 @@ static int service_running_and_authorized(const oracle* o, int target, int port,
     return 0;
 }
 
+/* __is_passing_firewall_rules (actions.py:504-515): the first rule naming the port decides; no rule = blocked */
+static int list_of(const oracle* o, int node, int dir) { return (int)((o->NS[node].fw_lists >> (dir ? 16 : 0)) & 0xFFFFu); }
+static int is_passing_firewall_rules(const oracle* o, const oenv* e, int node, int dir, int port_name) {
+    int l = list_of(o, node, dir);
+    for (int i = 0; i < e->n_fwl[l]; ++i)
+        if (e->fwl[l][i].name == port_name) return e->fwl[l][i].allow ? 1 : 0;
+    return 0;
+}
+
 /* connect_to_remote_machine (actions.py:524-606) */
 static action_result connect_to_remote_machine(const oracle* o, oenv* e, int source, int target, int port, int cred) {
     if (!e->node[source].agent_installed) return result(P_INVALID_ACTION, MCBS_OUT_NONE);
     if (!e->node[target].tracked) return result(P_INVALID_ACTION, MCBS_OUT_NONE);
     if (!e->gathered[cred]) return result(P_INVALID_ACTION, MCBS_OUT_NONE);
-    if (!((o->NS[source].fw_out_allow >> port) & 1u)) return result(P_BLOCKED_BY_LOCAL_FIREWALL, MCBS_OUT_NONE);
-    if (!((o->NS[target].fw_in_allow >> port) & 1u)) return result(P_BLOCKED_BY_REMOTE_FIREWALL, MCBS_OUT_NONE);
+    if (!is_passing_firewall_rules(o, e, source, 1, port)) return result(P_BLOCKED_BY_LOCAL_FIREWALL, MCBS_OUT_NONE);
+    if (!is_passing_firewall_rules(o, e, target, 0, port)) return result(P_BLOCKED_BY_REMOTE_FIREWALL, MCBS_OUT_NONE);
     int listening = 0;                                   /* port_name in [i.name for i in target_node.services] */
     for (int i = 0; i < o->NS[target].svc_cnt; ++i) if (o->SV[o->NS[target].svc_off + i].port == port) listening = 1;
     if (!listening) return result(P_SCANNING_UNOPEN_PORT, MCBS_OUT_NONE);
@@ -352,6 +366,10 @@ static void reset_env(const oracle* o, oenv* e) { /* __reset_environment (env.py
     e->clock = 0; e->stepcount = 0; e->done = 0; e->truncated = 0; e->episode_reward_sum = 0.0; e->availability = 1.0;
     e->last_kind = MCBS_OUT_NONE; e->last_level = 0; e->last_new_nodes = e->last_new_creds = 0; e->last_oob = 0;
     memset(e->gathered, 0, sizeof(int) * (o->H->n_cred_strings + 1));
+    for (uint32_t l = 0; l < o->H->n_fw_lists; ++l) {          /* copy.deepcopy(initial_environment) keeps list aliasing */
+        e->n_fwl[l] = o->FWRANGE[l * 2 + 1];
+        memcpy(e->fwl[l], o->FWR + o->FWRANGE[l * 2], sizeof(mcbs_fw_rule) * (size_t)e->n_fwl[l]);
+    }
     for (int n = 0; n < N; ++n) {
         onode* x = &e->node[n];
         memset(x, 0, sizeof(*x));
@@ -490,13 +508,13 @@ static int step_env(const oracle* o, oenv* e, uint64_t env_gid, const int32_t a[
         }
         if (obs) write_observation(o, e, obs, 0, 0, cache_before);
         reward = r.reward;
-        if (o->cfg.defender_kind != MCBS_DEFENDER_NONE) {
+        if (o->cfg.defender_kind == MCBS_DEFENDER_SCAN_AND_REIMAGE) {
             draws d = { o, e, env_gid, tape, tape_len, 0 };
             on_attacker_step_taken(o, e);
             defender_step(o, e, &d);
         }
         /* goals (env.py:1080-1116,1162-1169) */
-        int owned = owned_count(o, e), N = (int)o->H->n_nodes, has_def = o->cfg.defender_kind != MCBS_DEFENDER_NONE;
+        int owned = owned_count(o, e), N = (int)o->H->n_nodes, has_def = o->cfg.defender_kind == MCBS_DEFENDER_SCAN_AND_REIMAGE;
         int attacker_goal = 0;
         if (o->cfg.has_attacker_goal) {
             attacker_goal = 1;
@@ -523,6 +541,72 @@ static int step_env(const oracle* o, oenv* e, uint64_t env_gid, const int32_t a[
     return 0;
 }
 
+/* ---------------- learned defender: DefenderEnvWrapper.is_defender_action_valid (defend_wrapper.py:329-412) and
+ * LearningDefender.executeAction (marlon/defender_agents/defender.py:31-107), acting on the live environment ---------------- */
+static int rule_exists(const oenv* e, int l, int name) {
+    for (int i = 0; i < e->n_fwl[l]; ++i) if (e->fwl[l][i].name == name) return 1;
+    return 0;
+}
+
+static void defender_turn(const oracle* o, oenv* e, const int64_t a[12], int* valid, double* availability, int* evicted) {
+    int N = (int)o->H->n_nodes, kind = (int)a[0], ok = 0, node = -1;
+    static const int node_slot[5] = { 1, 2, 5, 8, 10 };
+    if (kind >= 0 && kind <= 4) node = (int)a[node_slot[kind]];
+    if (kind < 0) ok = 1;                                                            /* empty action: valid no-op */
+    else if (kind <= 4 && node >= 0 && node < N && e->node[node].status == ST_RUNNING) {
+        if (kind == 0) ok = (o->NS[node].flags & MCBS_NODE_REIMAGABLE) != 0;
+        else if (kind == 1) ok = a[3] >= 0 && a[3] < 6 && rule_exists(e, list_of(o, node, a[4] ? 0 : 1), o->H->rule_name[a[3]]);
+        else if (kind == 2) ok = 1;
+        else if (kind == 3) ok = a[9] >= 0 && a[9] < o->NS[node].svc_cnt;
+        else ok = a[11] >= 0 && a[11] < o->NS[node].svc_cnt;
+    }
+    on_attacker_step_taken(o, e);                                                    /* executeAction always starts with it */
+    if (ok && kind >= 0) {
+        if (kind == 0) reimage_node(e, node);
+        else if (kind == 1) {                                                        /* block_traffic: drop every rule naming the port */
+            int l = list_of(o, node, a[4] ? 0 : 1), name = o->H->rule_name[a[3]], w = 0;
+            for (int i = 0; i < e->n_fwl[l]; ++i) if (e->fwl[l][i].name != name) e->fwl[l][w++] = e->fwl[l][i];
+            e->n_fwl[l] = w;
+        } else if (kind == 2 && a[6] >= 0 && a[6] < 6) {                             /* allow_traffic: sic, appends to INCOMING in both cases */
+            int examined = list_of(o, node, a[7] ? 0 : 1), target = list_of(o, node, 0), name = o->H->rule_name[a[6]];
+            if (!rule_exists(e, examined, name)) {
+                e->fwl[target][e->n_fwl[target]].name = (uint8_t)name; e->fwl[target][e->n_fwl[target]].allow = 1; e->n_fwl[target]++;
+            }
+        }
+        /* stop_service / start_service: the reference passes a ListeningService where a port name is expected, nothing matches */
+    }
+    *valid = ok;
+    *availability = e->availability;
+    *evicted = o->cfg.defender_goal_eviction && owned_count(o, e) == 0;
+}
+
+void cbo_defender_step(void* h, const int64_t* actions, uint8_t* valid, double* availability, uint8_t* evicted) {
+    oracle* o = (oracle*)h;
+    for (int i = 0; i < o->n_envs; ++i) {
+        int v = 0, ev = 0; double av = o->env[i].availability;
+        if (actions[(size_t)i * 12] > -2) defender_turn(o, &o->env[i], actions + (size_t)i * 12, &v, &av, &ev);
+        if (valid) valid[i] = (uint8_t)v;
+        if (availability) availability[i] = av;
+        if (evicted) evicted[i] = (uint8_t)ev;
+    }
+}
+
+/* DefenderEnvWrapper.observe (defend_wrapper.py:492-534) */
+void cbo_defender_observe(void* h, int8_t* infected, int8_t* fw_in, int8_t* fw_out, int8_t* services) {
+    oracle* o = (oracle*)h; int N = (int)o->H->n_nodes;
+    for (int i = 0; i < o->n_envs; ++i) {
+        const oenv* e = &o->env[i];
+        for (int n = 0; n < N; ++n) {
+            if (infected) infected[(size_t)i * N + n] = (int8_t)e->node[n].agent_installed;
+            for (int k = 0; k < 6; ++k) {
+                if (fw_in) fw_in[((size_t)i * N + n) * 6 + k] = (int8_t)rule_exists(e, list_of(o, n, 0), o->H->rule_name[k]);
+                if (fw_out) fw_out[((size_t)i * N + n) * 6 + k] = (int8_t)rule_exists(e, list_of(o, n, 1), o->H->rule_name[k]);
+            }
+        }
+        if (services) for (uint32_t k = 0; k < o->H->n_services; ++k) services[(size_t)i * o->H->n_services + k] = (int8_t)(o->SV[k].running ? 1 : 0);
+    }
+}
+
 /* =============================== exported API (ctypes) =============================== */
 void* cbo_create(const void* blob, size_t nbytes, const mcbs_batch_cfg* cfg) {
     if (nbytes < sizeof(mcbs_topo_header)) return NULL;
@@ -541,6 +625,8 @@ void* cbo_create(const void* blob, size_t nbytes, const mcbs_batch_cfg* cfg) {
     o->AL = (const uint16_t*)(o->blob + o->H->off_allowed);
     o->TR = (const mcbs_triple*)(o->blob + o->H->off_triple);
     o->CODE = o->blob + o->H->off_code;
+    o->FWR = (const mcbs_fw_rule*)(o->blob + o->H->off_fw_rule);
+    o->FWRANGE = (const uint16_t*)(o->blob + o->H->off_fw_range);
     o->cfg = *cfg;
     o->n_envs = (int)cfg->n_envs;
     o->env = (oenv*)calloc((size_t)o->n_envs, sizeof(oenv));
@@ -548,6 +634,10 @@ void* cbo_create(const void* blob, size_t nbytes, const mcbs_batch_cfg* cfg) {
     for (int i = 0; i < o->n_envs; ++i) {
         oenv* e = &o->env[i];
         e->node = (onode*)calloc((size_t)N, sizeof(onode));
+        e->fwl = (mcbs_fw_rule**)calloc((size_t)o->H->n_fw_lists + 1, sizeof(mcbs_fw_rule*));
+        e->n_fwl = (int*)calloc((size_t)o->H->n_fw_lists + 1, sizeof(int));
+        for (uint32_t l = 0; l < o->H->n_fw_lists; ++l)          /* room for every rule the learned defender can append */
+            e->fwl[l] = (mcbs_fw_rule*)calloc((size_t)o->FWRANGE[l * 2 + 1] + 16u * N + 64, sizeof(mcbs_fw_rule));
         e->tracked_order = (int*)calloc((size_t)N, sizeof(int));
         e->discovered = (int*)calloc((size_t)N, sizeof(int));
         e->cache = (int*)calloc((size_t)o->H->n_triples + 1, sizeof(int));
@@ -562,6 +652,8 @@ void cbo_destroy(void* h) {
     oracle* o = (oracle*)h;
     if (!o) return;
     for (int i = 0; i < o->n_envs; ++i) {
+        for (uint32_t l = 0; l < o->H->n_fw_lists; ++l) free(o->env[i].fwl[l]);
+        free(o->env[i].fwl); free(o->env[i].n_fwl);
         free(o->env[i].node); free(o->env[i].tracked_order); free(o->env[i].discovered); free(o->env[i].cache); free(o->env[i].gathered);
     }
     free(o->env); free(o->blob); free(o);

@@ -55,6 +55,8 @@ def _load():
     lib.cbo_state_record_bytes.argtypes = [C.c_void_p]
     lib.cbo_get_state.argtypes = [C.c_void_p, C.c_void_p]
     lib.cbo_philox.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.cbo_defender_step.argtypes = [C.c_void_p] * 5
+    lib.cbo_defender_observe.argtypes = [C.c_void_p] * 5
     _lib = lib
     return lib
 
@@ -165,6 +167,21 @@ class Oracle:
 
     def reimage_node(self, node: int, env: int = 0) -> None:
         self.lib.cbo_reimage_node(self.h, env, node)
+
+    # -- learned defender (DefenderEnvWrapper + LearningDefender) --
+    def defender_step(self, actions12: np.ndarray) -> dict:
+        a = np.ascontiguousarray(actions12, dtype=np.int64).reshape(self.E, 12)
+        out = dict(valid=np.zeros(self.E, np.uint8), availability=np.zeros(self.E, np.float64), evicted=np.zeros(self.E, np.uint8))
+        self.lib.cbo_defender_step(self.h, a.ctypes.data, out["valid"].ctypes.data, out["availability"].ctypes.data, out["evicted"].ctypes.data)
+        return out
+
+    def defender_observe(self) -> dict:
+        N, S = self.topo.n_nodes, int(self.topo.header()["n_services"])
+        out = dict(infected_nodes=np.zeros((self.E, N), np.int8), incoming_firewall_status=np.zeros((self.E, N * 6), np.int8),
+                   outgoing_firewall_status=np.zeros((self.E, N * 6), np.int8), services_status=np.zeros((self.E, S), np.int8))
+        self.lib.cbo_defender_observe(self.h, *(out[k].ctypes.data for k in
+                                                ("infected_nodes", "incoming_firewall_status", "outgoing_firewall_status", "services_status")))
+        return out
 
     def get_state(self):
         rb = state_record_bytes(self.topo.n_nodes, self.spec.maximum_total_credentials)

@@ -122,5 +122,107 @@ def main():
     run("wrap_chain10_discrete_s64", chain10, sp_c, 300, 64, True, 100, 0)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "defender"):
     main()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Learned defender: DefenderEnvWrapper + LearningDefender next to the attacker wrapper on ONE CyberBattleEnv, as
+# MultiAgentUniverse.build wires them (multiagent_universe.py:160-199).  Quirk Q14: both defender objects capture
+# `environment` / `_defender_actuator` at construction while CyberBattleEnv.reset() replaces them, so after the first
+# reset the reference's defender acts on a dead copy.  The traces are captured with the defender RE-BOUND to the live
+# objects after every reset (instance attributes set from outside, source untouched): the behaviour the code intends and
+# the one this build implements.
+def run_defender(name, make_cyber_env, spec, steps, seed, max_timesteps):
+    from marlon.baseline_models.env_wrappers.defend_wrapper import DefenderEnvWrapper
+    from marlon.baseline_models.env_wrappers.environment_event_source import EnvironmentEventSource
+    rng = np.random.Generator(np.random.PCG64(seed))
+    cyber = make_cyber_env()
+    events = EnvironmentEventSource()
+    aw = AttackerEnvWrapper(cyber, event_source=events, max_timesteps=max_timesteps, invalid_action_reward_modifier=-1)
+    dw = DefenderEnvWrapper(cyber, attacker_reward_store=aw, event_source=events, defender=True, max_timesteps=max_timesteps,
+                            invalid_action_reward=-1, reset_on_constraint_broken=True, loss_reward=-5000.0)
+
+    def rebind():
+        dw._actuator = cyber._defender_actuator
+        dw.defender._actuator = cyber._defender_actuator
+        dw.defender._environment = cyber.environment
+
+    def reset_both(s):
+        obs, _ = aw.reset(seed=s)
+        rebind()
+        dobs, _ = dw.reset()          # reset_request was raised by the attacker's reset: no second notification; resets the env once
+                                      # more (as in the reference) and the defender's counters
+        rebind()
+        dw._prev_network_availability = float(dw._actuator.network_availability)
+        aw._last_transformed_observation = aw.transform_observation(cyber.reset(seed=s)[0])
+        rebind()
+        return dw.observe()
+
+    nvec_a, nvec_d = np.asarray(aw.action_space.nvec), np.asarray(dw.action_space.nvec)
+    dobs = reset_both(seed)
+    keys = ["infected_nodes", "incoming_firewall_status", "outgoing_firewall_status", "services_status"]
+    rec = {k: [] for k in ["a_action", "a_reward", "a_terminated", "a_truncated", "a_invalid", "d_action", "d_reward", "d_terminated",
+                           "d_truncated", "d_valid", "d_availability", "was_reset", "a_discovered"] + ["d_" + k for k in keys]}
+    first = {k: np.asarray(dobs[k], np.int8) for k in keys}
+    nodes = list(cyber.environment.network.nodes)
+    for t in range(steps):
+        a = (rng.random(10) * nvec_a).astype(np.int64)
+        nd = len(cyber._CyberBattleEnv__discovered_nodes)
+        if rng.random() < 0.8:
+            for i in (1, 3, 4, 6, 7):
+                a[i] = rng.integers(0, nd)
+            a[9] = rng.integers(0, max(1, len(cyber._CyberBattleEnv__credential_cache)))
+        obs, ar, aterm, atrunc, ainfo = aw.step(a)
+        rec["a_action"].append(a); rec["a_reward"].append(float(ar)); rec["a_terminated"].append(int(aterm))
+        rec["a_truncated"].append(int(atrunc)); rec["a_invalid"].append(int(bool(ainfo.get("invalid_action", False))))
+        rec["a_discovered"].append(int(obs["discovered_node_count"]))
+        d = (rng.random(12) * nvec_d).astype(np.int64)
+        r = rng.random()
+        if r < 0.35:                                  # bias toward re-imaging owned nodes so that the attacker feels it
+            owned = [i for i, n in enumerate(nodes) if cyber.environment.get_node(n).agent_installed]
+            d[0] = 0
+            d[1] = int(rng.choice(owned)) if owned and rng.random() < 0.7 else d[1]
+        done = bool(aterm or atrunc)
+        if not done:
+            dobs, dr, dterm, dtrunc, _ = dw.step(d)
+            rec["d_action"].append(d); rec["d_reward"].append(float(dr)); rec["d_terminated"].append(int(dterm))
+            rec["d_truncated"].append(int(dtrunc)); rec["d_valid"].append(int(bool(dw.last_action_valid)))
+            rec["d_availability"].append(float(dw.last_availability))
+            for k in keys:
+                rec["d_" + k].append(np.asarray(dobs[k], np.int8))
+            done = bool(dterm or dtrunc)
+        else:
+            rec["d_action"].append(np.full(12, -2, np.int64)); rec["d_reward"].append(0.0); rec["d_terminated"].append(0)
+            rec["d_truncated"].append(0); rec["d_valid"].append(0); rec["d_availability"].append(float(cyber._defender_actuator.network_availability))
+            for k in keys:
+                rec["d_" + k].append(np.asarray(dw.observe()[k], np.int8))
+        rec["was_reset"].append(int(done))
+        if done:
+            reset_both(seed + 1000 * (t + 1))
+    out = {k: np.asarray(v) for k, v in rec.items()}
+    for k in keys:
+        out["first_" + k] = first[k]
+    out["spec_json"] = np.frombuffer(json.dumps(dict(spec, max_timesteps=max_timesteps)).encode(), dtype=np.uint8)
+    path = os.path.join(G.GOLDEN, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name:28s} steps={steps} a_reward={out['a_reward'].sum():8.1f} d_reward={out['d_reward'].sum():9.1f} "
+          f"d_valid={out['d_valid'].sum():4d} resets={out['was_reset'].sum():3d} size={os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def main_defender():
+    AG, DC = ref.env.AttackerGoal, ref.env.DefenderConstraint
+    sp = dict(maximum_node_count=12, maximum_total_credentials=10, maximum_discoverable_credentials_per_action=5,
+              attacker_goal=dict(reward=0.0, low_availability=1.0, own_atleast=6, own_atleast_percent=1.0),
+              winning_reward=5000.0, losing_reward=-5000.0, maintain_sla=0.60, defender=["external"])
+
+    def toyctf_marl():   # multiagent_universe.py:160-165: no in-env defender_agent, SLA 0.60, losing_reward -5000
+        return ref.CyberBattleToyCtf(attacker_goal=AG(own_atleast=6), defender_constraint=DC(maintain_sla=0.60), losing_reward=-5000.0,
+                                     maximum_node_count=12, maximum_total_credentials=10, throws_on_invalid_actions=False)
+    run_defender("wrap_defender_toyctf_s71", toyctf_marl, sp, 400, 71, 60)
+    run_defender("wrap_defender_toyctf_s72", toyctf_marl, sp, 400, 72, 150)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "defender":
+        main_defender()

@@ -215,3 +215,81 @@ def test_run_episodes_random_policy_finishes_chain4():
     assert r.min() >= 0.0 and r.sum() > 0                         # masked actions are never intercepted (no -1 modifier)
     assert out["returns"].cpu().numpy().min() >= 0.0
     env.close()
+
+
+# ---------------------------------------------------------------- learned defender
+DEF_KEYS = ["infected_nodes", "incoming_firewall_status", "outgoing_firewall_status", "services_status"]
+
+
+@pytest.mark.parametrize("name", ["wrap_defender_toyctf_s71", "wrap_defender_toyctf_s72"])
+def test_defender_vec_env_matches_marlon_defender_wrapper(name):
+    """AttackerVecEnv + DefenderVecEnv on one batch == AttackerEnvWrapper + DefenderEnvWrapper/LearningDefender on one
+    CyberBattleEnv (defender re-bound to the live environment, quirk Q14): validity, firewall edits, re-imaging and its
+    effect on the attacker, availability, the shaped reward (fp64), SLA termination, eviction, truncation, observation."""
+    from marlon_amd import cyberbattle_env as ce
+    from marlon_amd.wrappers import AttackerVecEnv, DefenderVecEnv
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    sj = json.loads(bytes(z["spec_json"]).decode())
+    att = AttackerVecEnv(parity.topology_for("toyctf"), 1, maximum_node_count=12, maximum_total_credentials=10,
+                         attacker_goal=ce.AttackerGoal(**sj["attacker_goal"]), defender_constraint=ce.DefenderConstraint(sj["maintain_sla"]),
+                         losing_reward=sj["losing_reward"], max_timesteps=sj["max_timesteps"], auto_reset=False, learned_defender=True)
+    dfd = DefenderVecEnv(att, max_timesteps=sj["max_timesteps"], invalid_action_reward=-1, loss_reward=-5000.0)
+    for k in DEF_KEYS:
+        np.testing.assert_array_equal(dfd.observation[k][0].cpu().numpy(), z["first_" + k], err_msg=f"{name} first {k}")
+    for t in range(len(z["a_reward"])):
+        ctx = f"{name} step {t}"
+        obs, r, term, trunc, info = att.step(z["a_action"][t].reshape(1, 10))
+        assert float(r[0]) == z["a_reward"][t], f"{ctx}: attacker reward {float(r[0])} != {z['a_reward'][t]}"
+        assert int(term[0]) == z["a_terminated"][t] and int(trunc[0]) == z["a_truncated"][t], ctx + " attacker flags"
+        assert int(info["invalid_action"][0]) == z["a_invalid"][t] and int(obs["discovered_node_count"][0]) == z["a_discovered"][t], ctx
+        if z["d_action"][t][0] > -2:
+            dobs, dr, dterm, dtrunc, dinfo = dfd.step(z["d_action"][t].reshape(1, 12))
+            assert int(dinfo["valid_action"][0]) == z["d_valid"][t], ctx + f" validity of {z['d_action'][t].tolist()}"
+            assert float(dinfo["network_availability"][0]) == z["d_availability"][t], ctx + " availability"
+            assert float(dr[0]) == z["d_reward"][t], f"{ctx}: defender reward {float(dr[0])!r} != {z['d_reward'][t]!r}"
+            assert int(dterm[0]) == z["d_terminated"][t] and int(dtrunc[0]) == z["d_truncated"][t], ctx + " defender flags"
+            for k in DEF_KEYS:
+                np.testing.assert_array_equal(dobs[k][0].cpu().numpy(), z["d_" + k][t], err_msg=f"{ctx} {k}")
+        if z["was_reset"][t]:
+            att.reset()
+            dfd.reset()
+    att.close()
+
+
+def test_defender_step_batch_against_oracle():
+    """2 048 ToyCtf envs, random attacker rows and random defender vectors: validity, availability bits, eviction, the four
+    observation fields and the attacker's rewards equal the oracle's (which keeps real rule lists) at every step."""
+    from marlon_amd._abi import EnvSpec
+    from oracle.oracle import Oracle
+    topo = parity.topology_for("toyctf")
+    E, T = 2048, 120
+    spec = EnvSpec(n_envs=E, maximum_node_count=12, maximum_total_credentials=10, attacker_goal=dict(own_atleast=6, own_atleast_percent=1.0),
+                   maintain_sla=0.6, losing_reward=-5000.0, defender=("external",), auto_reset=True, max_episode_steps=80, seed=4)
+    eng = _engine_mod().BatchEngine(topo, spec)
+    orc = Oracle(topo, spec)
+    rng = np.random.Generator(np.random.PCG64(9))
+    nvec = np.array([5, 10, 10, 6, 2, 10, 6, 2, 10, 3, 10, 3])
+    dobs = eng.alloc_defender_obs()
+    for t in range(T):
+        a = eng.sample_actions(t % 4 != 0, seed=2, step=t)
+        r, d = eng.step(a)
+        o = orc.step(a.cpu().numpy())
+        np.testing.assert_array_equal(r.double().cpu().numpy(), o["reward"], err_msg=f"step {t} attacker reward")
+        np.testing.assert_array_equal(d.cpu().numpy(), o["terminated"], err_msg=f"step {t} terminated")
+        da = (rng.random((E, 12)) * nvec).astype(np.int64)
+        da[rng.random(E) < 0.05, 0] = -1
+        da[rng.random(E) < 0.05, 0] = -2
+        v, av, ev = eng.defender_step(da, dobs)
+        od = orc.defender_step(da)
+        np.testing.assert_array_equal(v.cpu().numpy(), od["valid"], err_msg=f"step {t} valid")
+        np.testing.assert_array_equal(av.cpu().numpy().view(np.uint64), od["availability"].view(np.uint64), err_msg=f"step {t} availability")
+        np.testing.assert_array_equal(ev.cpu().numpy(), od["evicted"], err_msg=f"step {t} evicted")
+        oo = orc.defender_observe()
+        for k in DEF_KEYS:
+            np.testing.assert_array_equal(dobs[k].cpu().numpy(), oo[k], err_msg=f"step {t} {k}")
+    eng.close()
+
+
+def _engine_mod():
+    from marlon_amd import engine
+    return engine
