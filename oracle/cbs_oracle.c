@@ -705,6 +705,24 @@ int cbo_step(void* h, const int32_t* actions, double* reward, uint8_t* terminate
     return errors;
 }
 
+/* Timing helper for bench.py's cpu_baseline leg: K consecutive steps of envs [env_lo, env_hi), env-major (every env's
+ * state stays cache-resident for its K steps: the CPU's best case), rewards summed per env.  actions [K, E, 5].
+ * Envs never interact, so disjoint ranges may run on different threads of the same handle. */
+int cbo_run(void* h, const int32_t* actions, int K, int env_lo, int env_hi, double* reward_sum) {
+    oracle* o = (oracle*)h; int errors = 0;
+    for (int i = env_lo; i < env_hi; ++i) {
+        double acc = 0.0;
+        for (int t = 0; t < K; ++t) {
+            ostep r;
+            if (step_env(o, &o->env[i], o->cfg.env_id_base + (uint64_t)i, actions + ((size_t)t * o->n_envs + (size_t)i) * 5,
+                         NULL, 0, NULL, &r) != 0) errors++;
+            acc += r.reward;
+        }
+        reward_sum[i] = acc;
+    }
+    return errors;
+}
+
 /* Actuator-level entry points (AgentActions without the gym env), to replay commandcontrol_test.py and
  * actions_test.py.  Nodes by network index, vulnerabilities by identifier-list index, credential by string id.
  * out[0] = reward, out[1] = outcome kind. */
