@@ -34,7 +34,7 @@ static int fail(int code, const char* fmt, ...) {
         if (_e != hipSuccess) return fail(MCBS_EHIP, "%s failed: %s", #expr, hipGetErrorString(_e));      \
     } while (0)
 
-struct HotLayout { uint32_t node, desc, payload, service, allowed, triple, avail, fwlist, bytes; };
+struct HotLayout { uint32_t node, desc, payload, auth, auth_words, triple, avail, fwlist, bytes; };
 
 struct mcbs_topology {
     std::vector<uint8_t> host;
@@ -146,11 +146,15 @@ extern "C" int mcbs_topology_create(const void* blob, size_t nbytes, int32_t dev
         uint32_t off = 0;
         auto take = [&](size_t bytes) { uint32_t o = off; off = (uint32_t)((off + bytes + 15) / 16 * 16); return o; };
         L.node = take(sizeof(HotNode) * N);
-        L.desc = take(sizeof(HotDesc) * (size_t)N * W);
-        L.payload = take(sizeof(mcbs_payload) * h->n_payload);
-        L.service = take(sizeof(mcbs_service) * h->n_services);
-        L.allowed = take(sizeof(uint16_t) * h->n_allowed);
-        L.triple = take(sizeof(mcbs_triple) * h->n_triples);
+        // every section holds at least one (zero) record: the step kernel looks tables up with clamped indices for every lane
+        L.desc = take(sizeof(HotDesc) * ((size_t)N * W + 1));
+        L.payload = take(sizeof(mcbs_payload) * (h->n_payload + 1));
+        // authorisation table replacing the service / allowed-credential lists (actions.py:608-621): per (node, port) the set
+        // of credential strings that some RUNNING service on that port accepts (service state never changes, mcbs_defend.hip)
+        const uint32_t P1 = h->n_ports ? h->n_ports : 1u;
+        L.auth_words = (h->n_cred_strings + 63u) / 64u ? (h->n_cred_strings + 63u) / 64u : 1u;
+        L.auth = take(sizeof(uint64_t) * (size_t)N * P1 * L.auth_words);
+        L.triple = take(sizeof(mcbs_triple) * (h->n_triples + 1));
         L.avail = take(sizeof(double) * N);
         L.fwlist = take(sizeof(uint32_t) * N);
         L.bytes = off;
@@ -176,8 +180,16 @@ extern "C" int mcbs_topology_create(const void* blob, size_t nbytes, int32_t dev
             }
         }
         memcpy(hb + L.payload, pl, sizeof(mcbs_payload) * h->n_payload);
-        memcpy(hb + L.service, sv, sizeof(mcbs_service) * h->n_services);
-        memcpy(hb + L.allowed, b + h->off_allowed, sizeof(uint16_t) * h->n_allowed);
+        const uint16_t* allowed = reinterpret_cast<const uint16_t*>(b + h->off_allowed);
+        uint64_t* auth = reinterpret_cast<uint64_t*>(hb + L.auth);
+        for (uint32_t n = 0; n < N; ++n)
+            for (uint32_t i = ns[n].svc_off; i < (uint32_t)ns[n].svc_off + ns[n].svc_cnt; ++i) {
+                if (!sv[i].running) continue;
+                for (uint32_t k = 0; k < sv[i].allowed_cnt; ++k) {
+                    const uint32_t c = allowed[sv[i].allowed_off + k];
+                    if (c < h->n_cred_strings) auth[((size_t)n * P1 + sv[i].port) * L.auth_words + (c >> 6)] |= 1ull << (c & 63u);
+                }
+            }
         memcpy(hb + L.triple, tr, sizeof(mcbs_triple) * h->n_triples);
     }
     hipError_t e = hipSetDevice(device);
@@ -241,8 +253,9 @@ extern "C" int mcbs_batch_create(const mcbs_topology* topo, const mcbs_batch_cfg
     S.TW = (h->n_triples + 63) / 64; if (!S.TW) S.TW = 1;
     S.Cmax = cfg->maximum_total_credentials;
     S.off_disc = 0;                                                             // u8 discovery order, >= 16 bytes
-    S.off_cred = (uint32_t)align_up((size_t)N, 16);                             // u16 credential cache, >= 32 bytes
-    S.off_rows = (uint32_t)align_up((size_t)S.off_cred + (2u * h->n_triples > 32u ? 2u * h->n_triples : 32u), 16);
+    // both lists have one slack entry past their capacity: the step kernel appends unconditionally and only advances the count
+    S.off_cred = (uint32_t)align_up((size_t)N + 1, 16);                         // u16 credential cache, >= 32 bytes
+    S.off_rows = (uint32_t)align_up((size_t)S.off_cred + (2u * (h->n_triples + 1u) > 32u ? 2u * (h->n_triples + 1u) : 32u), 16);
     const bool external = cfg->defender_kind == MCBS_DEFENDER_EXTERNAL;
     S.off_fw = external ? (uint32_t)align_up((size_t)S.off_rows + sizeof(Row) * N, 16) : 0u;
     S.body_stride = (uint32_t)align_up(external ? (size_t)S.off_fw + 2u * h->n_fw_lists : (size_t)S.off_rows + sizeof(Row) * N, 64);
@@ -304,9 +317,9 @@ extern "C" int mcbs_batch_create(const mcbs_topology* topo, const mcbs_batch_cfg
     C.K = cfg->maximum_discoverable_credentials_per_action;
     C.off_node = h->off_node; C.off_slot_of = h->off_slot_of; C.off_slot = h->off_slot; C.off_payload = h->off_payload;
     C.off_service = h->off_service; C.off_allowed = h->off_allowed; C.off_triple = h->off_triple;
-    C.hot_node = topo->hot.node; C.hot_desc = topo->hot.desc; C.hot_payload = topo->hot.payload; C.hot_service = topo->hot.service;
+    C.hot_node = topo->hot.node; C.hot_desc = topo->hot.desc; C.hot_payload = topo->hot.payload; C.hot_auth = topo->hot.auth;
     memcpy(C.rule_port, h->rule_port, 8); C.n_services = h->n_services; C.n_fw_lists = h->n_fw_lists; C.hot_fwlist = topo->hot.fwlist;
-    C.hot_allowed = topo->hot.allowed; C.hot_triple = topo->hot.triple; C.hot_avail = topo->hot.avail; C.hot_bytes = topo->hot.bytes;
+    C.auth_words = topo->hot.auth_words; C.hot_triple = topo->hot.triple; C.hot_avail = topo->hot.avail; C.hot_bytes = topo->hot.bytes;
 
     e = hipMalloc(&b->C_dev, sizeof(StepCfg));
     if (e == hipSuccess) e = hipMemcpy(b->C_dev, &b->C, sizeof(StepCfg), hipMemcpyHostToDevice);

@@ -93,7 +93,7 @@ struct StepCfg {        // the parts of mcbs_batch_cfg the kernels read
     // section offsets into the blob, hoisted so kernels do not chase the header
     uint32_t off_node, off_slot_of, off_slot, off_payload, off_service, off_allowed, off_triple;
     // hot image (Topo::hot) section offsets and size
-    uint32_t hot_node, hot_desc, hot_payload, hot_service, hot_allowed, hot_triple, hot_avail, hot_bytes;
+    uint32_t hot_node, hot_desc, hot_payload, hot_auth, auth_words, hot_triple, hot_avail, hot_bytes;
     uint8_t  rule_port[8];   // identifier-port index of RDP, SSH, HTTPS, HTTP, su, sudo (0xFF: not an identifier port)
     uint32_t n_services, n_fw_lists;
     uint32_t hot_fwlist;     // uint32[N]: incoming list id | outgoing list id << 16

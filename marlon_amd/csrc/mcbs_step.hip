@@ -16,13 +16,22 @@
 //           EVERY set of the env as u64 bit-mask words (discovered, agent installed, ever owned, running,
 //           privilege bit-planes, gathered credentials, cached credential triples), {cum_reward, availability};
 //           meanwhile the workgroup copies the topology tables into LDS;
-//   level 2 (address depends on the action / header): the target node's 32-byte row, the re-imaging ring slot
+//   level 2 (address depends on the action / header): the target node's 16-byte row, the re-imaging ring slot
 //           of this defender tick (and list entries beyond the first 16 for large topologies);
-//   then pure register + LDS work (vulnerability slot, payload, firewall / service tables, Philox), and one
-//   round of stores (row, changed masks, list appends, header, outputs).  "Rare" events are not rare per
-//   wavefront (64 envs), so nothing on those paths may cost another trip to memory: a first version that
-//   tested the ever-owned / discovered / credential sets lazily in memory spent 9 of its 10 dependency levels
-//   there (profiles/round1_notes.md).
+//   then pure register + LDS work (vulnerability descriptor, payload, firewall / authorisation tables, Philox), and
+//   one round of stores (row, sets, list appends, header, outputs).  "Rare" events are not rare per wavefront
+//   (64 envs), so nothing on those paths may cost another trip to memory: a first version that tested the
+//   ever-owned / discovered / credential sets lazily in memory spent 9 of its 10 dependency levels there
+//   (profiles/round1_notes.md).
+//
+// Control flow.  The lanes of a wavefront hold different action kinds, outcomes and validity, so every `if` of the
+// reference that the compiler keeps as a branch is paid by the whole wave (compare, exec-mask save, branch, restore:
+// four single-issue instructions at one wave per SIMD) whether or not any lane takes it.  The attacker's action is
+// therefore written as straight-line predicated arithmetic: indices are clamped so that every look-up is safe for
+// every lane, both the connect-side and the exploit-side tables are read, every check of the reference becomes a
+// boolean, and the state changes are masked by the conjunction (`go`).  Loads and stores are unconditional wherever
+// storing the unchanged value back is harmless.  What remains as real branches: the payload loop of leaked
+// credentials / nodes, list entries past the first 16, the in-env defender, and the wave-level auto-reset.
 //
 // Rules restated from the reference (citations = /root/reference/src/CyberBattleSim/cyberbattle/...):
 //   _env/cyberbattle_env.py : step 1145-1185, __execute_action 707-751, index translation 584-601,
@@ -65,9 +74,24 @@ __device__ __forceinline__ bool rtestset(uint64_t (&m)[WT], uint32_t n) {
     rset<WT>(m, n);
     return was;
 }
+// predicated forms for the straight-line attacker path: the bit of element n as a WT-word set, empty when !on
+template <int WT>
+__device__ __forceinline__ void rbit(uint64_t (&b)[WT], uint32_t n, bool on) {
+    const uint64_t bit = on ? (1ull << (n & 63u)) : 0ull;
+#pragma unroll
+    for (int i = 0; i < WT; ++i) b[i] = (WT == 1 || (n >> 6) == (uint32_t)i) ? bit : 0ull;
+}
 
-__device__ __forceinline__ uint32_t pick4(const uint4& v, uint32_t i) {
-    return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w;
+// entry i (< 16) of a 16-byte vector of u8, and of two 16-byte vectors of u16 (entries 0..7 | 8..15)
+__device__ __forceinline__ uint32_t byte_of(const uint4& v, uint32_t i) {
+    const uint32_t lo = (i & 4u) ? v.y : v.x, hi = (i & 4u) ? v.w : v.z;
+    return (((i & 8u) ? hi : lo) >> ((i & 3u) * 8u)) & 0xFFu;
+}
+__device__ __forceinline__ uint32_t half_of(const uint4& a, const uint4& b, uint32_t i) {
+    const uint32_t a01 = (i & 2u) ? a.y : a.x, a23 = (i & 2u) ? a.w : a.z;
+    const uint32_t b01 = (i & 2u) ? b.y : b.x, b23 = (i & 2u) ? b.w : b.z;
+    const uint32_t wa = (i & 4u) ? a23 : a01, wb = (i & 4u) ? b23 : b01;
+    return (((i & 8u) ? wb : wa) >> ((i & 1u) * 16u)) & 0xFFFFu;
 }
 
 // ------------------------------ per-lane working set ------------------------------
@@ -80,11 +104,11 @@ struct Lane {
     uint8_t* body;
     uint32_t n_disc, n_creds, owned, dclk;
     uint64_t m[M_COUNT][WT];
-    uint32_t dirty;      // bit k: set k changed and must be written back
+    uint32_t dirty;      // defender paths: bit k = set k changed and must be written back
     // the target node's row, in registers
     uint64_t props;      // discovered properties (60 bits)
     uint32_t ever, since, tags;
-    bool row_dirty;
+    bool row_dirty;      // (unused by the step kernel: the row is always written back)
     // learned-defender tier: this env's firewall state of source / target (12 bits per rule list, see mcbs_defend.hip), else unused
     bool learned;
     uint32_t fw_src, fw_tgt;
@@ -96,7 +120,6 @@ struct Lane {
     __device__ __forceinline__ Row* row(uint32_t n) const { return reinterpret_cast<Row*>(body + S.off_rows) + n; }
     __device__ __forceinline__ uint8_t* disc_list() const { return body + S.off_disc; }
     __device__ __forceinline__ uint16_t* cred_list() const { return reinterpret_cast<uint16_t*>(body + S.off_cred); }
-    __device__ __forceinline__ void done_with(double r, int kind) { raw = r; okind = kind; }
 
     __device__ __forceinline__ uint32_t privilege(uint32_t n) const {
         return (uint32_t)rget<WT>(m[M_PLO], n) | ((uint32_t)rget<WT>(m[M_PHI], n) << 1);
@@ -109,121 +132,119 @@ struct Lane {
 
     // One action of one env: AgentActions.exploit_local_vulnerability / exploit_remote_vulnerability (actions.py:473-502,
     // 425-471) -> __process_outcome (325-423) with __mark_discovered_entities (277-310), and connect_to_remote_machine
-    // (524-606), merged into one flow so that the ownership change (__mark_node_as_owned, 251-275) and the bookkeeping
-    // exist once in the instruction stream: lanes of a wavefront hold different action kinds and every divergent copy
-    // of a block is paid by the whole wave.  kind: 0 local, 1 remote, 2 connect; `col` = vulnerability column (exploits),
-    // `port` / `triple` = connect arguments.
-    __device__ __forceinline__ void act(int kind, uint32_t src, uint32_t tgt, uint32_t col, uint32_t port, uint32_t triple) {
-        // Phase A — every check of the reference, evaluated without early exits and folded by priority into
-        // (proceed, raw, okind): keeps the wavefront's control flow two levels deep instead of one level per check.
-        const HotNode* t = NS(tgt);
+    // (524-606), as ONE predicated flow (see "Control flow" above).
+    //   X      : the env executes this action (live env, indices in range, credential index inside the cache)
+    //   raw_nx : the raw reward when !X (0 out of bounds, -1 credential index outside the cache; env.py:736-737)
+    //   kind   : 0 local, 1 remote, 2 connect; `col` = vulnerability column (exploits; 0 for connect),
+    //            `port` / `triple` = connect arguments (0 for exploits).  Every index is valid for every lane.
+    __device__ __forceinline__ void act(bool X, double raw_nx, int kind, uint32_t src, uint32_t tgt, uint32_t col, uint32_t port, uint32_t triple) {
+        const bool k2 = kind == 2;
+        // ---- look-ups of both flavours (LDS) ----
+        const uint4* tp = reinterpret_cast<const uint4*>(NS(tgt));
+        const uint4 t0 = tp[0], t1 = tp[1];              // {props lo, hi, value, fw_in_allow} {fw_out_allow, listen, svc, flags}
+        const uint64_t t_props = (uint64_t)t0.x | ((uint64_t)t0.y << 32);
+        const int t_value = (int)t0.z;
+        const uint32_t src_fw_out = NS(src)->fw_out_allow;
+        const uint32_t cred = (reinterpret_cast<const mcbs_triple*>(tb + C.hot_triple) + triple)->cred;
+        const uint64_t auth = reinterpret_cast<const uint64_t*>(tb + C.hot_auth)[(tgt * C.P + port) * C.auth_words + (cred >> 6)];
+        const uint4* dp = reinterpret_cast<const uint4*>(tb + C.hot_desc + (tgt * (C.L + C.R) + col) * (uint32_t)sizeof(HotDesc));
+        const uint4 d0 = dp[0], d1 = dp[1];   // {cost lo,hi, probe lo,hi} {payload_off, cnt | tt << 16, kind | level << 8 | slot << 16, -}
+
         const bool src_owned = rget<WT>(m[M_INST], src);
         const bool running = rget<WT>(m[M_RUN], tgt);
-        bool proceed, want_own = false;
-        uint32_t own_level = 1u, slot_bit = 0u, payload_off = 0u, payload_cnt = 0u, okind_ok = MCBS_OUT_LATERAL_MOVE;
-        uint64_t probe = 0ull;
-        double cost = 0.0, fail_raw;
-        int fail_kind = MCBS_OUT_NONE, lvl_out = 0;
-        if (kind == 2) {
-            // target is discovered and the credential gathered by construction (both come from this env's own lists)
-            const uint32_t cred = (reinterpret_cast<const mcbs_triple*>(tb + C.hot_triple) + triple)->cred;
-            bool out_ok = (NS(src)->fw_out_allow >> port) & 1u, in_ok = (t->fw_in_allow >> port) & 1u;
-            if (learned) {                                   // a manageable rule name: the env's own rule state decides
-#pragma unroll
-                for (uint32_t r = 0; r < 6u; ++r)
-                    if (C.rule_port[r] == port) {
-                        out_ok = ((fw_src >> r) & (fw_src >> (6u + r)) & 1u) != 0;   // fw_src: the source's OUTGOING list
-                        in_ok = ((fw_tgt >> r) & (fw_tgt >> (6u + r)) & 1u) != 0;    // fw_tgt: the target's INCOMING list
-                    }
-            }
-            const bool fw_ok = out_ok && in_ok;                                                           // BLOCKED_BY_LOCAL/REMOTE_FIREWALL
-            const bool listening = (t->listen >> port) & 1u;                                              // SCANNING_UNOPEN_PORT
-            bool authorized = false;                                                                      // actions.py:608-621
-            const mcbs_service* sv = reinterpret_cast<const mcbs_service*>(tb + C.hot_service) + t->svc_off;
-            const uint16_t* allowed = reinterpret_cast<const uint16_t*>(tb + C.hot_allowed);
-            const uint32_t nsv = t->svc_cnt;
-            for (uint32_t i = 0; i < nsv; ++i) {
-                const bool match = sv[i].running && sv[i].port == port;
-                const uint32_t ao = sv[i].allowed_off, ac = match ? sv[i].allowed_cnt : 0u;
-                for (uint32_t k = 0; k < ac; ++k) authorized |= (allowed[ao + k] == cred);
-            }
-            // order of the reference: firewalls (-10), listening (-10), running (0), credentials (-10: WRONG_PASSWORD)
-            proceed = fw_ok && listening && running && authorized;
-            fail_raw = (fw_ok && listening && !running) ? 0.0 : -10.0;
-            want_own = true;
-        } else {
-            const uint4* dp = reinterpret_cast<const uint4*>(tb + C.hot_desc + (tgt * (C.L + C.R) + col) * (uint32_t)sizeof(HotDesc));
-            const uint4 d0 = dp[0], d1 = dp[1];   // {cost lo,hi, probe lo,hi} {payload_off, cnt | tt << 16, kind | level << 8 | slot << 16, -}
-            const uint32_t vk = d1.z & 0xFFu, level = (d1.z >> 8) & 0xFFu;
-            const bool present = vk != 0xFFu;
-            const bool pre_ok = ((d1.y >> 16) >> tags) & 1u;                                              // precondition on (static props, tags)
-            const bool esc = vk == MCBS_OUT_PRIVILEGE_ESCALATION;
-            const bool repeat_esc = esc && ((tags >> level) & 1u);                                        // tag already on the node
-            proceed = running && present && pre_ok && !repeat_esc;
-            // MACHINE_NOT_RUNNING 0 > SUPSPICIOUSNESS -5 > LOCAL_EXPLOIT_FAILED -20 / FAILED_REMOTE_EXPLOIT -50 > REPEAT -1
-            fail_raw = !running ? 0.0 : (!present ? -5.0 : (!pre_ok ? (kind == 0 ? -20.0 : -50.0) : -1.0));
-            fail_kind = (running && present) ? (!pre_ok ? MCBS_OUT_EXPLOIT_FAILED : MCBS_OUT_PRIVILEGE_ESCALATION) : MCBS_OUT_NONE;
-            lvl_out = (running && present && pre_ok && esc) ? (int)level : 0;
-            okind_ok = vk;
-            want_own = esc || vk == MCBS_OUT_LATERAL_MOVE;
-            own_level = esc ? level : 1u;
-            probe = vk == MCBS_OUT_PROBE_SUCCEEDED ? ((uint64_t)d0.z | ((uint64_t)d0.w << 32)) : 0ull;
-            slot_bit = 1u << ((d1.z >> 16) & 0x1Fu);
-            payload_off = d1.x; payload_cnt = d1.y & 0xFFFFu;
-            cost = __hiloint2double((int)d0.y, (int)d0.x);
-        }
-        if (!src_owned) return done_with(-1.0, MCBS_OUT_NONE);                                            // INVALID_ACTION, checked first
-        olevel = lvl_out;
-        if (!proceed) return done_with(fail_raw, fail_kind);
+        const bool already = rget<WT>(m[M_INST], tgt);
 
-        // Phase B — __mark_node_as_owned (actions.py:251-275): `already` = currently owned (agent installed); a node that
-        // is owned now was owned before, so only a change of ownership consults / sets the ever-owned bit
-        int r = 0;
-        if (want_own) {
-            const bool already = rget<WT>(m[M_INST], tgt);
-            bool owned_before = true;
-            if (!already) {
-                owned_before = rtestset<WT>(m[M_EVER], tgt);
-                rset<WT>(m[M_INST], tgt);
-                dirty |= (1u << M_EVER) | (1u << M_INST);
-                const uint32_t priv = privilege(tgt);
-                const uint32_t np = priv > own_level ? priv : own_level;   // model.escalate
-                if (np != priv) { set_privilege(tgt, np); if (priv == 0u) owned += 1; }
-                props |= t->props;                                          // all (non-tag) properties become known
-                row_dirty = true;
+        // ---- connect_to_remote_machine checks, in the reference's order: firewalls (-10), listening (-10), running (0),
+        // credentials (-10: WRONG_PASSWORD); target discovered / credential gathered hold by construction (own lists) ----
+        bool out_ok = (src_fw_out >> port) & 1u, in_ok = (t0.w >> port) & 1u;
+        if (learned) {                                       // a manageable rule name: the env's own rule state decides
+#pragma unroll
+            for (uint32_t r = 0; r < 6u; ++r) {
+                const bool mine = C.rule_port[r] == port;
+                out_ok = mine ? (((fw_src >> r) & (fw_src >> (6u + r)) & 1u) != 0) : out_ok;   // fw_src: the source's OUTGOING list
+                in_ok = mine ? (((fw_tgt >> r) & (fw_tgt >> (6u + r)) & 1u) != 0) : in_ok;     // fw_tgt: the target's INCOMING list
             }
-            if (kind == 2) {
-                if (already) return done_with(-1.0, MCBS_OUT_LATERAL_MOVE);                        // REPEAT
-                return done_with(owned_before ? 0.0 : (double)t->value, MCBS_OUT_LATERAL_MOVE);
-            }
-            if (!owned_before) r += t->value;
-            if (okind_ok == MCBS_OUT_PRIVILEGE_ESCALATION) tags |= 1u << own_level;
         }
-        // Phase C — exploit bookkeeping (actions.py:386-423)
-        r += 2 * __popcll(probe & ~props);
+        const bool reach = out_ok & in_ok & (bool)((t1.y >> port) & 1u);                        // not BLOCKED_BY_*_FIREWALL, not SCANNING_UNOPEN_PORT
+        const bool authorized = (auth >> (cred & 63u)) & 1ull;                                  // actions.py:608-621, precomputed per (node, port)
+        const bool c_proceed = reach & running & authorized;
+        const double c_fail_raw = (reach & !running) ? 0.0 : -10.0;
+
+        // ---- exploit checks: MACHINE_NOT_RUNNING 0 > SUPSPICIOUSNESS -5 > LOCAL_EXPLOIT_FAILED -20 / FAILED_REMOTE_EXPLOIT -50 > REPEAT -1 ----
+        const uint32_t vk = d1.z & 0xFFu, level = (d1.z >> 8) & 0xFFu;
+        const bool present = vk != 0xFFu;
+        const bool pre_ok = ((d1.y >> 16) >> tags) & 1u;                                        // precondition on (static props, tags)
+        const bool esc = !k2 & (vk == MCBS_OUT_PRIVILEGE_ESCALATION);
+        const bool repeat_esc = esc & (bool)((tags >> level) & 1u);                             // tag already on the node
+        const bool x_proceed = running & present & pre_ok & !repeat_esc;
+        const double x_fail_raw = !running ? 0.0 : (!present ? -5.0 : (!pre_ok ? (kind == 0 ? -20.0 : -50.0) : -1.0));
+        const int x_fail_kind = (running & present) ? (!pre_ok ? MCBS_OUT_EXPLOIT_FAILED : MCBS_OUT_PRIVILEGE_ESCALATION) : MCBS_OUT_NONE;
+        const int x_lvl = (running & present & pre_ok & esc) ? (int)level : 0;
+
+        const bool so = X & src_owned;                          // else INVALID_ACTION (-1), checked first
+        const bool go = so & (k2 ? c_proceed : x_proceed);      // the action takes effect
+        const bool xb = go & !k2;                               // ... and is an exploit
+        const uint32_t vk_ok = k2 ? (uint32_t)MCBS_OUT_LATERAL_MOVE : vk;
+        const uint32_t own_level = esc ? level : 1u;
+
+        // ---- __mark_node_as_owned (actions.py:251-275): `already` = currently owned (agent installed); a node that is
+        // owned now was owned before, so only a change of ownership consults / sets the ever-owned bit ----
+        const bool newly = go & !already & (k2 | esc | (vk == MCBS_OUT_LATERAL_MOVE));
+        const bool first_time = newly & !rget<WT>(m[M_EVER], tgt);
+        const uint32_t priv = privilege(tgt);
+        const uint32_t np = priv > own_level ? priv : own_level;   // model.escalate
+        const bool chg = newly & (np != priv);
+        uint64_t bn[WT], bc[WT];
+        rbit<WT>(bn, tgt, newly);
+        rbit<WT>(bc, tgt, chg);
+#pragma unroll
+        for (int w = 0; w < WT; ++w) {
+            m[M_EVER][w] |= bn[w];
+            m[M_INST][w] |= bn[w];
+            m[M_PLO][w] = (m[M_PLO][w] & ~bc[w]) | ((np & 1u) ? bc[w] : 0ull);
+            m[M_PHI][w] = (m[M_PHI][w] & ~bc[w]) | ((np & 2u) ? bc[w] : 0ull);
+        }
+        owned += (chg & (priv == 0u)) ? 1u : 0u;
+        props |= newly ? t_props : 0ull;                        // all (non-tag) properties become known
+        tags |= (xb & esc) ? (1u << own_level) : 0u;
+
+        // ---- exploit bookkeeping (actions.py:386-423) ----
+        int r = first_time ? t_value : 0;                       // (connect uses it below)
+        const uint64_t probe = (xb & (vk == MCBS_OUT_PROBE_SUCCEEDED)) ? ((uint64_t)d0.z | ((uint64_t)d0.w << 32)) : 0ull;
+        int rx = r + 2 * __popcll(probe & ~props);
         props |= probe;
-        if (ever & slot_bit) { if (since & slot_bit) r -= 1; } else r += 7;
-        ever |= slot_bit; since |= slot_bit;
-        row_dirty = true;
-        int nn = 0, nc = 0;
-        const bool creds = okind_ok == MCBS_OUT_LEAKED_CREDENTIALS;
-        if (creds || okind_ok == MCBS_OUT_LEAKED_NODES) {
-            const uint2* pl = reinterpret_cast<const uint2*>(tb + C.hot_payload) + payload_off;
-            for (uint32_t i = 0; i < payload_cnt; ++i) {
-                const uint2 p = pl[i];                   // {node | cred << 16, triple | port << 16}
-                const uint32_t pn = p.x & 0xFFFFu;
-                if (!rtestset<WT>(m[M_DISC], pn)) { disc_list()[n_disc++] = (uint8_t)pn; nn++; dirty |= 1u << M_DISC; }
-                if (creds) {
-                    if (!rtestset<WT>(m[M_GATH], p.x >> 16)) { nc++; dirty |= 1u << M_GATH; }
-                    if (!rtestset<WT>(m[M_CACH], p.y & 0xFFFFu)) {
-                        cred_list()[n_creds++] = (uint16_t)(p.y & 0xFFFFu); new_creds++; dirty |= 1u << M_CACH;
-                    }
-                }
-            }
+        const uint32_t sb = xb ? (1u << ((d1.z >> 16) & 0x1Fu)) : 0u;
+        rx += (ever & sb) ? ((since & sb) ? -1 : 0) : (xb ? 7 : 0);
+        ever |= sb; since |= sb;
+        const bool creds = vk == MCBS_OUT_LEAKED_CREDENTIALS;
+        const uint32_t cnt = (xb & (creds | (vk == MCBS_OUT_LEAKED_NODES))) ? (d1.y & 0xFFFFu) : 0u;
+        const uint2* pl = reinterpret_cast<const uint2*>(tb + C.hot_payload) + d1.x;
+        uint32_t nn = 0, nc = 0, ncache = 0;
+        for (uint32_t i = 0; i < cnt; ++i) {
+            const uint2 p = pl[i];                       // {node | cred << 16, triple | port << 16}
+            const uint32_t pn = p.x & 0xFFFFu, pc = p.x >> 16, pt = p.y & 0xFFFFu;
+            // appends go to the slot past the list's end whether or not the element is new (the lists have one slack slot):
+            // the count only advances for a new element, so a stale write is overwritten or never read
+            const bool new_n = !rget<WT>(m[M_DISC], pn);
+            const bool new_g = creds & !rget<WT>(m[M_GATH], pc);
+            const bool new_c = creds & !rget<WT>(m[M_CACH], pt);
+            disc_list()[n_disc] = (uint8_t)pn;
+            cred_list()[n_creds] = (uint16_t)pt;
+            uint64_t b0[WT], b1[WT], b2[WT];
+            rbit<WT>(b0, pn, new_n); rbit<WT>(b1, pc, new_g); rbit<WT>(b2, pt, new_c);
+#pragma unroll
+            for (int w = 0; w < WT; ++w) { m[M_DISC][w] |= b0[w]; m[M_GATH][w] |= b1[w]; m[M_CACH][w] |= b2[w]; }
+            n_disc += new_n; nn += new_n; nc += new_g; n_creds += new_c; ncache += new_c;
         }
-        new_nodes = nn;
-        r += 5 * nn + 3 * nc;
-        done_with((double)r - cost, (int)okind_ok);
+        rx += 5 * (int)nn + 3 * (int)nc;
+        const double x_raw = (double)rx - __hiloint2double((int)d0.y, (int)d0.x);
+        const double c_raw = already ? -1.0 : (double)r;                                       // REPEAT, else the node's value the first time
+
+        raw = !X ? raw_nx : (!src_owned ? -1.0 : (!go ? (k2 ? c_fail_raw : x_fail_raw) : (k2 ? c_raw : x_raw)));
+        okind = go ? (int)vk_ok : ((so & !k2) ? x_fail_kind : MCBS_OUT_NONE);
+        olevel = (so & !k2) ? x_lvl : 0;
+        new_nodes = (int)nn;
+        new_creds = (int)ncache;
     }
 
     // ---- defender ----
@@ -341,10 +362,12 @@ __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, const Ste
     }
     double2 h1 = make_double2(0.0, 0.0);
     uint32_t episode = 0;
+    double pending = 0.0;
     if (PHASE != 1) {
         h1 = S.h1[ec];
         if (has_def && C.rng_kind == MCBS_RNG_PHILOX) episode = S.episode[ec];
     }
+    if (PHASE == 2) pending = S.pending[ec];
 
     STAMP_NOWAIT(1);   // level-1 loads issued
     const uint8_t* tb = T.hot;
@@ -357,148 +380,132 @@ __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, const Ste
 
     STAMP(2);          // level-1 loads and the LDS copy have landed
     bool need_reset = false;
-    uint32_t step = h0.x, flags = h0.y;
-    // finished envs and skip actions (MCBS_ACTION_SKIP) leave the env untouched
-    const bool skip_env = (PHASE != 2 && (int)a03.x == MCBS_ACTION_SKIP) || (PHASE == 2 && (flags & F_SKIP));
-    if (active && PHASE == 1 && !(flags & (F_DONE | F_TRUNC))) {
-        const uint32_t nf = skip_env ? (flags | F_SKIP) : (flags & ~F_SKIP);
-        if (skip_env && nf != flags) S.h0[e].y = nf;
-    }
-    if (active && PHASE == 2 && (flags & F_SKIP)) S.h0[e].y = flags & ~F_SKIP;
-    if (active && ((flags & (F_DONE | F_TRUNC)) || skip_env)) {
-        // step after done: the reference raises RuntimeError (env.py:1146-1147); the batch leaves the env untouched
-        if (PHASE != 1) {
-            io.reward[e] = 0.0f;
-            io.terminated[e] = (uint8_t)((flags & F_DONE) ? 1 : 0);
-            if (io.truncated) io.truncated[e] = (uint8_t)((flags & F_TRUNC) ? 1 : 0);
-            if (io.availability) io.availability[e] = h1.y;
-            if (io.step_count) io.step_count[e] = (int32_t)step;
-            if (io.oob) io.oob[e] = 0;
-            if (io.raw_reward) io.raw_reward[e] = 0.0f;
-        }
-    } else if (active) {
-        Lane<WT> ln{S, C, tb, e, body, h0.z & 0xFFFFu, h0.z >> 16, h0.w & 0xFFFFu, h0.w >> 16, {}, 0u, 0ull, 0u, 0u, 0u, false, learned, 0u, 0u,
-                    0.0, MCBS_OUT_NONE, 0, 0, 0};
-#pragma unroll
-        for (int k = 0; k < M_COUNT; ++k)
-#pragma unroll
-            for (int w = 0; w < WT; ++w) ln.m[k][w] = m0[k][w];
-        // level 2 (needs the header): this defender tick's ring slot
-        uint64_t back[WT];
-#pragma unroll
-        for (int w = 0; w < WT; ++w)
-            back[w] = (PHASE != 1 && has_def) ? S.ring[((ln.dclk & 15u) * WT + (uint32_t)w) * S.E + e] : 0ull;
+    if (active) {   // (inactive lanes of the last wavefront still take part in the wave-level reset copy below)
+    const uint32_t old_flags = h0.y;
+    const bool ended = (old_flags & (F_DONE | F_TRUNC)) != 0;   // step after done: the reference raises RuntimeError
+                                                                // (env.py:1146-1147); the batch leaves the env untouched
+    // skip actions (MCBS_ACTION_SKIP) leave the env untouched too; a split step remembers them in F_SKIP for phase 2
+    const bool skip_env = PHASE == 2 ? (old_flags & F_SKIP) != 0 : (int)a03.x == MCBS_ACTION_SKIP;
+    const bool live = !ended & !skip_env;
 
-        bool oob = false;
-        if (PHASE != 2) {
-            // ---------------- __execute_action (cyberbattle_env.py:707-751) ----------------
-            step += 1;
-            const int kind = (int)a03.x, a1 = (int)a03.y, a2 = (int)a03.z, a3 = (int)a03.w, a4i = (int)a4;
-            const int nd = (int)ln.n_disc, ncr = (int)ln.n_creds;
-            bool skip = false;                                       // connect with a credential index outside the cache
-            if (kind == 0) oob = a1 < 0 || a1 >= nd || a2 < 0 || a2 >= (int)C.L;
-            else if (kind == 1) oob = a1 < 0 || a1 >= nd || a2 < 0 || a2 >= nd || a3 < 0 || a3 >= (int)C.R;
-            else if (kind == 2) {
-                skip = a4i < 0 || a4i >= ncr;                        // env.py:736-737, before any node look-up
-                oob = !skip && (a1 < 0 || a1 >= nd || a2 < 0 || a2 >= nd || a3 < 0 || a3 >= (int)C.P);
-            } else oob = true;
-            if (skip) ln.done_with(-1.0, MCBS_OUT_NONE);
-            else if (!oob) {
-                auto node_of = [&](int ext) -> uint32_t {
-                    if (ext < 16) return (pick4(dhead, (uint32_t)ext >> 2) >> (8u * ((uint32_t)ext & 3u))) & 0xFFu;
-                    return ln.disc_list()[ext];
-                };
-                const uint32_t src = node_of(a1);
-                const uint32_t tgt = kind == 0 ? src : node_of(a2);
-                // ---------------- level 2: the target row ----------------
-                const uint4 r0 = *reinterpret_cast<const uint4*>(ln.row(tgt));
-                const uint64_t pt = (uint64_t)r0.x | ((uint64_t)r0.y << 32);
-                ln.props = pt & ROW_PROPS_MASK; ln.tags = (uint32_t)(pt >> 60);
-                ln.ever = r0.z; ln.since = r0.w;
-                if (learned && kind == 2) {
-                    const uint16_t* fw = reinterpret_cast<const uint16_t*>(body + S.off_fw);
-                    const uint32_t* lists = reinterpret_cast<const uint32_t*>(tb + C.hot_fwlist);
-                    ln.fw_src = fw[lists[src] >> 16]; ln.fw_tgt = fw[lists[tgt] & 0xFFFFu];
-                }
-                STAMP(3);  // row landed
-                uint32_t triple = 0;
-                if (kind == 2) {
-                    if (a4i < 16) {
-                        const uint32_t d = a4i < 8 ? pick4(chead0, (uint32_t)a4i >> 1) : pick4(chead1, ((uint32_t)a4i - 8u) >> 1);
-                        triple = (d >> (16u * ((uint32_t)a4i & 1u))) & 0xFFFFu;
-                    } else triple = ln.cred_list()[a4i];
-                }
-                ln.act(kind, src, tgt, kind == 0 ? (uint32_t)a2 : C.L + (uint32_t)a3, (uint32_t)a3, triple);
-                if (ln.row_dirty) {
-                    const uint64_t wpt = ln.props | ((uint64_t)ln.tags << 60);
-                    *reinterpret_cast<uint4*>(ln.row(tgt)) = make_uint4((uint32_t)wpt, (uint32_t)(wpt >> 32), ln.ever, ln.since);
-                }
-            }
-            STAMP(4);      // attacker logic and row store done
-            if (oob) { ln.raw = 0.0; ln.okind = MCBS_OUT_NONE; ln.olevel = 0; ln.new_nodes = 0; ln.new_creds = 0; }
-            flags = (oob ? F_OOB : 0u) | ((uint32_t)ln.okind << F_KIND_SHIFT) | ((uint32_t)ln.olevel << F_LEVEL_SHIFT) |
-                    ((uint32_t)ln.new_nodes << F_NEWNODES_SHIFT) | ((uint32_t)ln.new_creds << F_NEWCREDS_SHIFT);
-        } else {
-            oob = (flags & F_OOB) != 0;
-            ln.raw = S.pending[e];
+    Lane<WT> ln{S, C, tb, ec, body, h0.z & 0xFFFFu, h0.z >> 16, h0.w & 0xFFFFu, h0.w >> 16, {}, 0u, 0ull, 0u, 0u, 0u, false, learned, 0u, 0u,
+                0.0, MCBS_OUT_NONE, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < M_COUNT; ++k)
+#pragma unroll
+        for (int w = 0; w < WT; ++w) ln.m[k][w] = m0[k][w];
+    // level 2 (needs the header): this defender tick's ring slot
+    uint64_t back[WT];
+#pragma unroll
+    for (int w = 0; w < WT; ++w)
+        back[w] = (PHASE != 1 && has_def) ? S.ring[((ln.dclk & 15u) * WT + (uint32_t)w) * S.E + ec] : 0ull;
+
+    uint32_t step = h0.x, flags = old_flags;
+    bool oob = false;
+    if (PHASE != 2) {
+        // ---------------- __execute_action (cyberbattle_env.py:707-751), index checks as booleans ----------------
+        const int kind = (int)a03.x;
+        const uint32_t a1 = a03.y, a2 = a03.z, a3 = a03.w;      // unsigned compares reject negative indices as well
+        const bool k0 = kind == 0, k1 = kind == 1, k2 = kind == 2;
+        const bool skip = k2 & (a4 >= ln.n_creds);              // connect with a credential index outside the cache: env.py:736-737,
+                                                                // before any node look-up
+        const bool bad = (a1 >= ln.n_disc) | (a2 >= (k0 ? C.L : ln.n_disc)) | (!k0 & (a3 >= (k1 ? C.R : C.P)));
+        oob = live & (!(k0 | k1 | k2) | (!skip & bad));
+        const bool X = live & !skip & !oob & (k0 | k1 | k2);
+        // indices every lane may use: its own when the action executes, entry 0 otherwise
+        const uint32_t i1 = X ? a1 : 0u, i2 = (X & !k0) ? a2 : i1, i4 = (X & k2) ? a4 : 0u;
+        uint32_t src = byte_of(dhead, i1 & 15u), tgt = byte_of(dhead, i2 & 15u);
+        uint32_t triple = half_of(chead0, chead1, i4 & 15u);
+        if ((i1 | i2 | i4) >= 16u) {                            // large topologies: entries past the first 16 of a list
+            const uint32_t s2 = ln.disc_list()[i1], t2 = ln.disc_list()[i2], c2 = ln.cred_list()[i4];
+            src = i1 >= 16u ? s2 : src; tgt = i2 >= 16u ? t2 : tgt; triple = i4 >= 16u ? c2 : triple;
         }
-        if (PHASE == 1) {
-            S.pending[e] = ln.raw;
-            S.h0[e] = make_uint4(step, flags, ln.n_disc | (ln.n_creds << 16), ln.owned | (ln.dclk << 16));
-        } else {
-            double reward = 0.0;
-            bool done = false;
-            if (!oob) {
-                if (has_def) {
-                    uint64_t fresh[WT];
+        // ---------------- level 2: the target row ----------------
+        const uint4 r0 = *reinterpret_cast<const uint4*>(ln.row(tgt));
+        if (learned) {
+            const uint16_t* fw = reinterpret_cast<const uint16_t*>(body + S.off_fw);
+            const uint32_t* lists = reinterpret_cast<const uint32_t*>(tb + C.hot_fwlist);
+            ln.fw_src = fw[lists[src] >> 16]; ln.fw_tgt = fw[lists[tgt] & 0xFFFFu];
+        }
+        const uint64_t pt = (uint64_t)r0.x | ((uint64_t)r0.y << 32);
+        ln.props = pt & ROW_PROPS_MASK; ln.tags = (uint32_t)(pt >> 60);
+        ln.ever = r0.z; ln.since = r0.w;
+        STAMP(3);  // row landed
+        ln.act(X, skip ? -1.0 : 0.0, kind, src, tgt, X ? (k0 ? a2 : (k1 ? C.L + a3 : 0u)) : 0u, (X & k2) ? a3 : 0u, triple);
+        const uint64_t wpt = ln.props | ((uint64_t)ln.tags << 60);   // unchanged rows are written back as they were
+        *reinterpret_cast<uint4*>(ln.row(tgt)) = make_uint4((uint32_t)wpt, (uint32_t)(wpt >> 32), ln.ever, ln.since);
+        STAMP(4);      // attacker logic and row store done
+        const uint32_t nf = (oob ? F_OOB : 0u) | ((uint32_t)ln.okind << F_KIND_SHIFT) | ((uint32_t)ln.olevel << F_LEVEL_SHIFT) |
+                            ((uint32_t)ln.new_nodes << F_NEWNODES_SHIFT) | ((uint32_t)ln.new_creds << F_NEWCREDS_SHIFT);
+        flags = live ? nf : ((PHASE == 1 && !ended && skip_env) ? (old_flags | F_SKIP) : old_flags);
+        step += live ? 1u : 0u;
+    } else {
+        oob = live & ((old_flags & F_OOB) != 0);
+        ln.raw = pending;
+        flags = old_flags & ~F_SKIP;
+    }
+
+    if (PHASE == 1) {
+        if (live) S.pending[e] = ln.raw;
+        S.h0[e] = make_uint4(step, flags, ln.n_disc | (ln.n_creds << 16), ln.owned | (ln.dclk << 16));
+    } else {
+        double reward = 0.0;
+        bool done = false;
+        if (has_def) {
+            if (live & !oob) {
+                uint64_t fresh[WT];
 #pragma unroll
-                    for (int w = 0; w < WT; ++w) fresh[w] = 0ull;
-                    h1.y = ln.defender_tick(back);
-                    ln.defender_scan(step, episode, io, fresh);
+                for (int w = 0; w < WT; ++w) fresh[w] = 0ull;
+                h1.y = ln.defender_tick(back);
+                ln.defender_scan(step, episode, io, fresh);
 #pragma unroll
-                    for (int w = 0; w < WT; ++w)       // the slot now holds the nodes re-imaged at this tick (released 16 ticks on)
-                        if (fresh[w] != back[w]) S.ring[((ln.dclk & 15u) * WT + (uint32_t)w) * S.E + e] = fresh[w];
-                    ln.dclk = (ln.dclk + 1u) & 0xFFFFu;
-                }
-                // goals (env.py:1080-1116) on the state AFTER the defender acted, availability from BEFORE its scan
-                bool attacker_goal = C.has_attacker_goal != 0;
-                if (attacker_goal) {
-                    if (h1.x < C.goal_reward) attacker_goal = false;
-                    else if (ln.owned < C.goal_own_atleast) attacker_goal = false;
-                    else if ((double)ln.owned / (double)S.N < C.goal_own_atleast_percent) attacker_goal = false;
-                    else if (has_def && h1.y >= C.goal_low_availability) attacker_goal = false;
-                }
-                const bool sla_broken = has_def && h1.y < C.maintain_sla;
-                const bool evicted = C.defender_goal_eviction && ln.owned == 0;
-                if (attacker_goal || sla_broken) { done = true; reward = C.winning_reward; }
-                else if (evicted) { done = true; reward = C.losing_reward; }
-                else reward = ln.raw > 0.0 ? ln.raw : 0.0;                                  // max(0, reward), env.py:1169
+                for (int w = 0; w < WT; ++w)       // the slot now holds the nodes re-imaged at this tick (released 16 ticks on)
+                    if (fresh[w] != back[w]) S.ring[((ln.dclk & 15u) * WT + (uint32_t)w) * S.E + e] = fresh[w];
+                ln.dclk = (ln.dclk + 1u) & 0xFFFFu;
             }
-            h1.x += reward;
-            const bool trunc = !done && C.max_episode_steps && step >= C.max_episode_steps;
+        }
+        {
+            // goals (env.py:1080-1116) on the state AFTER the defender acted, availability from BEFORE its scan
+            const bool attacker_goal = (C.has_attacker_goal != 0) & !(h1.x < C.goal_reward) & !(ln.owned < C.goal_own_atleast) &
+                                       !((double)ln.owned / (double)S.N < C.goal_own_atleast_percent) &
+                                       !(has_def && h1.y >= C.goal_low_availability);
+            const bool sla_broken = has_def && h1.y < C.maintain_sla;
+            const bool evicted = (C.defender_goal_eviction != 0) & (ln.owned == 0);
+            const bool win = attacker_goal | sla_broken;
+            const bool play = live & !oob;
+            done = play & (win | evicted);
+            const double r_play = win ? C.winning_reward : (evicted ? C.losing_reward : (ln.raw > 0.0 ? ln.raw : 0.0));   // max(0, reward), env.py:1169
+            reward = play ? r_play : 0.0;
+        }
+        h1.x += reward;
+        const bool trunc = live & !done & (C.max_episode_steps != 0) & (step >= C.max_episode_steps);
+        {
             io.reward[e] = (float)reward;
-            io.terminated[e] = done ? 1 : 0;
-            if (io.truncated) io.truncated[e] = trunc ? 1 : 0;
+            io.terminated[e] = live ? (done ? 1 : 0) : (uint8_t)((old_flags & F_DONE) ? 1 : 0);
+            if (io.truncated) io.truncated[e] = live ? (trunc ? 1 : 0) : (uint8_t)((old_flags & F_TRUNC) ? 1 : 0);
             if (io.availability) io.availability[e] = h1.y;
             if (io.step_count) io.step_count[e] = (int32_t)step;
             if (io.oob) io.oob[e] = oob ? 1 : 0;
-            if (io.raw_reward) io.raw_reward[e] = (float)ln.raw;
-            if ((done || trunc) && C.auto_reset) need_reset = true;
-            else {
-                flags |= (done ? F_DONE : 0u) | (trunc ? F_TRUNC : 0u);
-                S.h0[e] = make_uint4(step, flags, ln.n_disc | (ln.n_creds << 16), ln.owned | (ln.dclk << 16));
-                S.h1[e] = h1;
-            }
+            if (io.raw_reward) io.raw_reward[e] = live ? (float)ln.raw : 0.0f;
+            need_reset = (done | trunc) & (C.auto_reset != 0);
+            flags |= (done ? F_DONE : 0u) | (trunc ? F_TRUNC : 0u);
+            S.h0[e] = make_uint4(step, flags, ln.n_disc | (ln.n_creds << 16), ln.owned | (ln.dclk << 16));
+            S.h1[e] = h1;
         }
-        if (!need_reset && ln.dirty) {
+    }
+    {
+        // sets the phase can have changed go back whole (WT == 1: one coalesced 8-byte store per set beats a compare and a
+        // branch); an env about to be reset gets its columns rewritten below, after these stores in program order
 #pragma unroll
-            for (int k = 0; k < M_COUNT; ++k) {
-                if (!((ln.dirty >> k) & 1u)) continue;
+        for (int k = 0; k < M_COUNT; ++k) {
+            const bool attacker_set = k != M_RUN;
+            const bool defender_set = k == M_RUN || k == M_INST || k == M_PLO || k == M_PHI;
+            if (!((PHASE != 2 && attacker_set) || (PHASE != 1 && has_def && defender_set))) continue;
 #pragma unroll
-                for (int w = 0; w < WT; ++w)
-                    if (WT == 1 || ln.m[k][w] != m0[k][w]) S.masks[((uint32_t)k * WT + (uint32_t)w) * S.E + e] = ln.m[k][w];
-            }
+            for (int w = 0; w < WT; ++w)
+                if (WT == 1 || ln.m[k][w] != m0[k][w]) S.masks[((uint32_t)k * WT + (uint32_t)w) * S.E + e] = ln.m[k][w];
         }
+    }
     }
     STAMP(5);              // all stores of the step retired
     if (PHASE != 1) {
