@@ -51,22 +51,27 @@
 namespace mcbs {
 
 // ------------------------------ sets held in registers (WT words each) ------------------------------
+// (word selection is written as mask arithmetic, not as a select chain: the compiler turns a chain of selects over m[0..WT)
+// into a dynamically indexed stack array, i.e. scratch memory round trips, for WT == 4)
+__device__ __forceinline__ uint64_t word_is(uint32_t n, int i) { return 0ull - (uint64_t)((n >> 6) == (uint32_t)i); }
 template <int WT>
 __device__ __forceinline__ bool rget(const uint64_t (&m)[WT], uint32_t n) {
-    uint64_t w = m[0];
+    uint64_t w = WT == 1 ? m[0] : 0ull;
+    if (WT > 1) {
 #pragma unroll
-    for (int i = 1; i < WT; ++i) if ((n >> 6) == (uint32_t)i) w = m[i];
+        for (int i = 0; i < WT; ++i) w |= m[i] & word_is(n, i);
+    }
     return (w >> (n & 63u)) & 1ull;
 }
 template <int WT>
 __device__ __forceinline__ void rset(uint64_t (&m)[WT], uint32_t n) {
 #pragma unroll
-    for (int i = 0; i < WT; ++i) if ((n >> 6) == (uint32_t)i) m[i] |= 1ull << (n & 63u);
+    for (int i = 0; i < WT; ++i) m[i] |= (1ull << (n & 63u)) & (WT == 1 ? ~0ull : word_is(n, i));
 }
 template <int WT>
 __device__ __forceinline__ void rclear(uint64_t (&m)[WT], uint32_t n) {
 #pragma unroll
-    for (int i = 0; i < WT; ++i) if ((n >> 6) == (uint32_t)i) m[i] &= ~(1ull << (n & 63u));
+    for (int i = 0; i < WT; ++i) m[i] &= ~((1ull << (n & 63u)) & (WT == 1 ? ~0ull : word_is(n, i)));
 }
 template <int WT>   // returns the previous value of the bit
 __device__ __forceinline__ bool rtestset(uint64_t (&m)[WT], uint32_t n) {
@@ -79,19 +84,20 @@ template <int WT>
 __device__ __forceinline__ void rbit(uint64_t (&b)[WT], uint32_t n, bool on) {
     const uint64_t bit = on ? (1ull << (n & 63u)) : 0ull;
 #pragma unroll
-    for (int i = 0; i < WT; ++i) b[i] = (WT == 1 || (n >> 6) == (uint32_t)i) ? bit : 0ull;
+    for (int i = 0; i < WT; ++i) b[i] = bit & (WT == 1 ? ~0ull : word_is(n, i));
 }
 
-// entry i (< 16) of a 16-byte vector of u8, and of two 16-byte vectors of u16 (entries 0..7 | 8..15)
+// entry i (< 16) of a 16-byte vector of u8, and of two 16-byte vectors of u16 (entries 0..7 | 8..15); written with 64-bit
+// shifts so that the compiler keeps the vectors in registers (a select tree over the four dwords becomes a stack array)
 __device__ __forceinline__ uint32_t byte_of(const uint4& v, uint32_t i) {
-    const uint32_t lo = (i & 4u) ? v.y : v.x, hi = (i & 4u) ? v.w : v.z;
-    return (((i & 8u) ? hi : lo) >> ((i & 3u) * 8u)) & 0xFFu;
+    const uint64_t lo = (uint64_t)v.x | ((uint64_t)v.y << 32), hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
+    return (uint32_t)(((i & 8u) ? hi : lo) >> ((i & 7u) * 8u)) & 0xFFu;
 }
 __device__ __forceinline__ uint32_t half_of(const uint4& a, const uint4& b, uint32_t i) {
-    const uint32_t a01 = (i & 2u) ? a.y : a.x, a23 = (i & 2u) ? a.w : a.z;
-    const uint32_t b01 = (i & 2u) ? b.y : b.x, b23 = (i & 2u) ? b.w : b.z;
-    const uint32_t wa = (i & 4u) ? a23 : a01, wb = (i & 4u) ? b23 : b01;
-    return (((i & 8u) ? wb : wa) >> ((i & 1u) * 16u)) & 0xFFFFu;
+    const uint64_t a0 = (uint64_t)a.x | ((uint64_t)a.y << 32), a1 = (uint64_t)a.z | ((uint64_t)a.w << 32);
+    const uint64_t b0 = (uint64_t)b.x | ((uint64_t)b.y << 32), b1 = (uint64_t)b.z | ((uint64_t)b.w << 32);
+    const uint64_t wa = (i & 4u) ? a1 : a0, wb = (i & 4u) ? b1 : b0;
+    return (uint32_t)(((i & 8u) ? wb : wa) >> ((i & 3u) * 16u)) & 0xFFFFu;
 }
 
 // ------------------------------ per-lane working set ------------------------------
