@@ -266,7 +266,9 @@ extern "C" int mcbs_batch_create(const mcbs_topology* topo, const mcbs_batch_cfg
     uint32_t wt = S.NW > S.SW ? S.NW : S.SW;
     if (S.TW > wt) wt = S.TW;
     S.WT = wt <= 1 ? 1 : (wt == 2 ? 2 : 4);
-    const size_t o_masks = take(8ull * M_COUNT * S.WT * E);
+    // small topologies: the eight sets of an env as 16-bit fields of one 16-byte word (mcbs_device.h)
+    S.packed = (N <= 16u && h->n_cred_strings <= 16u && h->n_triples <= 16u && !getenv("MCBS_NO_PACKED_SETS")) ? 1u : 0u;
+    const size_t o_masks = take(S.packed ? 16ull * E : 8ull * M_COUNT * S.WT * E);
     const bool has_def = cfg->defender_kind != MCBS_DEFENDER_NONE;   // in-env or external: both re-image nodes
     const size_t o_ring = has_def ? take(8ull * 16 * S.WT * E) : 0;
     const size_t o_init = take(S.body_stride);
@@ -411,7 +413,8 @@ static void launch_step_nw(mcbs_batch* b, const StepIO& io, hipStream_t st) {
 
 template <int PHASE>
 static int launch_step(mcbs_batch* b, const StepIO& io, hipStream_t st, const char* what) {
-    if (b->S.WT == 1) launch_step_nw<PHASE, 1>(b, io, st);
+    if (b->S.packed) launch_step_nw<PHASE, 0>(b, io, st);       // WT 0: packed sets (one word of registers each)
+    else if (b->S.WT == 1) launch_step_nw<PHASE, 1>(b, io, st);
     else if (b->S.WT == 2) launch_step_nw<PHASE, 2>(b, io, st);
     else launch_step_nw<PHASE, 4>(b, io, st);
     return launch_ok(what);
@@ -600,8 +603,8 @@ extern "C" int mcbs_get_state(mcbs_batch* b, void* host_buf, size_t nbytes) {
     const uint4* h0 = reinterpret_cast<const uint4*>(at(S.h0));
     const double2* h1 = reinterpret_cast<const double2*>(at(S.h1));
     const uint32_t* ep = reinterpret_cast<const uint32_t*>(at(S.episode));
-    const uint64_t* mk[M_COUNT];
-    for (int k = 0; k < M_COUNT; ++k) mk[k] = reinterpret_cast<const uint64_t*>(at(S.mask(k)));
+    const void* mk = at(S.masks);
+    auto has = [&](int k, uint32_t n, uint32_t e) { return ((S.set_word(mk, k, n >> 6, e) >> (n & 63u)) & 1ull) != 0; };
     const uint64_t* ring = S.ring ? reinterpret_cast<const uint64_t*>(at(S.ring)) : nullptr;
     const uint8_t* body = at(S.body);
     memset(host_buf, 0, rb * S.E);
@@ -620,12 +623,11 @@ extern "C" int mcbs_get_state(mcbs_batch* b, void* host_buf, size_t nbytes) {
         for (uint32_t n = 0; n < S.N; ++n) {
             Row r;
             memcpy(&r, eb + S.off_rows + sizeof(Row) * n, sizeof(r));
-            const size_t k = (size_t)(n >> 6) * S.E + e;
             const uint64_t bit = 1ull << (n & 63u);
             sn[n].discovered_props = r.props_tags & ROW_PROPS_MASK; sn[n].attacked_ever = r.ever; sn[n].attacked_since = r.since;
-            sn[n].discovered = (mk[M_DISC][k] & bit) != 0; sn[n].installed = (mk[M_INST][k] & bit) != 0;
-            sn[n].ever_owned = (mk[M_EVER][k] & bit) != 0; sn[n].running = (mk[M_RUN][k] & bit) != 0;
-            sn[n].privilege = (uint8_t)(((mk[M_PLO][k] & bit) ? 1 : 0) | ((mk[M_PHI][k] & bit) ? 2 : 0));
+            sn[n].discovered = has(M_DISC, n, e); sn[n].installed = has(M_INST, n, e);
+            sn[n].ever_owned = has(M_EVER, n, e); sn[n].running = has(M_RUN, n, e);
+            sn[n].privilege = (uint8_t)((has(M_PLO, n, e) ? 1 : 0) | (has(M_PHI, n, e) ? 2 : 0));
             sn[n].tags = (uint8_t)(r.props_tags >> 60);
             sn[n].countdown = 0;
             if (!sn[n].running && ring) {   // remaining steps = distance from the defender clock to the node's ring slot
@@ -657,8 +659,8 @@ extern "C" int mcbs_set_state(mcbs_batch* b, const void* host_buf, size_t nbytes
     uint4* h0 = reinterpret_cast<uint4*>(at(S.h0));
     double2* h1 = reinterpret_cast<double2*>(at(S.h1));
     uint32_t* ep = reinterpret_cast<uint32_t*>(at(S.episode));
-    uint64_t* mk[M_COUNT];
-    for (int k = 0; k < M_COUNT; ++k) mk[k] = reinterpret_cast<uint64_t*>(at(S.mask(k)));
+    void* mk = at(S.masks);
+    auto add = [&](int k, uint32_t n, uint32_t e) { S.put_word(mk, k, n >> 6, e, S.set_word(mk, k, n >> 6, e) | (1ull << (n & 63u))); };
     uint64_t* ring = S.ring ? reinterpret_cast<uint64_t*>(at(S.ring)) : nullptr;
     uint8_t* body = at(S.body);
     const mcbs_triple* tr = reinterpret_cast<const mcbs_triple*>(b->topo->host.data() + th->off_triple);
@@ -670,22 +672,21 @@ extern "C" int mcbs_set_state(mcbs_batch* b, const void* host_buf, size_t nbytes
         const uint16_t* cc = order + S.N;
         if (sh->n_discovered > S.N || sh->n_creds > th->n_triples) return fail(MCBS_EINVAL, "env %u: list lengths out of range", e);
         for (uint32_t w = 0; w < S.WT; ++w) {
-            for (int k = 0; k < M_COUNT; ++k) mk[k][(size_t)w * S.E + e] = 0;
+            for (int k = 0; k < M_COUNT; ++k) S.put_word(mk, k, w, e, 0ull);
             if (ring) for (uint32_t s = 0; s < 16u; ++s) ring[((size_t)s * S.WT + w) * S.E + e] = 0;
         }
         uint8_t* eb = body + (size_t)e * S.body_stride;
         uint32_t owned = 0;
         const uint32_t dclk = h0[e].w >> 16;      // the defender clock is not part of the canonical record: keep the current phase
         for (uint32_t n = 0; n < S.N; ++n) {
-            const size_t k = (size_t)(n >> 6) * S.E + e;
             const uint64_t bit = 1ull << (n & 63u);
             if (sn[n].privilege > 3 || sn[n].countdown > 15) return fail(MCBS_EINVAL, "env %u node %u: bad privilege / countdown", e, n);
-            if (sn[n].discovered) mk[M_DISC][k] |= bit;
-            if (sn[n].installed) mk[M_INST][k] |= bit;
-            if (sn[n].ever_owned) mk[M_EVER][k] |= bit;
-            if (sn[n].running) mk[M_RUN][k] |= bit;
-            if (sn[n].privilege & 1) mk[M_PLO][k] |= bit;
-            if (sn[n].privilege & 2) mk[M_PHI][k] |= bit;
+            if (sn[n].discovered) add(M_DISC, n, e);
+            if (sn[n].installed) add(M_INST, n, e);
+            if (sn[n].ever_owned) add(M_EVER, n, e);
+            if (sn[n].running) add(M_RUN, n, e);
+            if (sn[n].privilege & 1) add(M_PLO, n, e);
+            if (sn[n].privilege & 2) add(M_PHI, n, e);
             owned += sn[n].privilege >= 1;
             if (!sn[n].running && ring) ring[((size_t)((dclk + sn[n].countdown) & 15u) * S.WT + (n >> 6)) * S.E + e] |= bit;
             Row r{};
@@ -701,9 +702,9 @@ extern "C" int mcbs_set_state(mcbs_batch* b, const void* host_buf, size_t nbytes
         for (uint32_t i = 0; i < sh->n_creds; ++i) {
             if (cc[i] >= th->n_triples) return fail(MCBS_EINVAL, "env %u: credential cache entry out of range", e);
             cl[i] = cc[i];
-            mk[M_CACH][(size_t)(cc[i] >> 6) * S.E + e] |= 1ull << (cc[i] & 63u);
+            add(M_CACH, cc[i], e);
             const uint32_t c = tr[cc[i]].cred;                     // a cached triple implies its credential string is gathered
-            mk[M_GATH][(size_t)(c >> 6) * S.E + e] |= 1ull << (c & 63u);
+            add(M_GATH, c, e);
         }
         const uint32_t flags = (sh->done ? F_DONE : 0u) | (sh->truncated ? F_TRUNC : 0u) | (sh->last_oob ? F_OOB : 0u) |
                                ((sh->last_outcome_kind & 0xFu) << F_KIND_SHIFT) | ((sh->last_escalation & 3u) << F_LEVEL_SHIFT) |

@@ -73,8 +73,7 @@ __global__ __launch_bounds__(128) void sample_kernel(DevState S, Topo T, StepCfg
             uint32_t k = below(owned);
             for (uint32_t i = 0; i < n_disc; ++i) {
                 const uint32_t n = dl[i];
-                const size_t q = (size_t)(n >> 6) * S.E + e;
-                if (((S.mask(M_PLO)[q] | S.mask(M_PHI)[q]) >> (n & 63u)) & 1ull) { if (k == 0) return i; k -= 1; }
+                if (S.has(M_PLO, n, e) || S.has(M_PHI, n, e)) { if (k == 0) return i; k -= 1; }
             }
             return 0u;
         };
@@ -82,7 +81,7 @@ __global__ __launch_bounds__(128) void sample_kernel(DevState S, Topo T, StepCfg
             const uint32_t kind = below(n_creds ? 3u : 2u);
             const uint32_t src = owned_source();
             const uint32_t node = dl[src];
-            const bool installed = (S.mask(M_INST)[(size_t)(node >> 6) * S.E + e] >> (node & 63u)) & 1ull;
+            const bool installed = S.has(M_INST, node, e);
             if (kind == 0) {
                 const uint32_t v = below(C.L);
                 a[0] = 0; a[1] = (int32_t)src; a[2] = (int32_t)v; a[3] = 0; a[4] = 0;

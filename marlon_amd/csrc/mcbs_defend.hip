@@ -33,7 +33,7 @@ __global__ __launch_bounds__(128) void defender_kernel(DevState S, Topo T, const
 #pragma unroll
         for (int w = 0; w < WT; ++w) {
             const bool wanted = k == M_INST || k == M_RUN || k == M_PLO || k == M_PHI;
-            m0[k][w] = wanted ? S.masks[((uint32_t)k * WT + (uint32_t)w) * S.E + e] : 0ull;
+            m0[k][w] = wanted ? S.get(k, (uint32_t)w, e) : 0ull;
             ln.m[k][w] = m0[k][w];
         }
     uint64_t back[WT], fresh[WT];
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(128) void defender_kernel(DevState S, Topo T, const
             if (!((ln.dirty >> k) & 1u)) continue;
 #pragma unroll
             for (int w = 0; w < WT; ++w)
-                if (WT == 1 || ln.m[k][w] != m0[k][w]) S.masks[((uint32_t)k * WT + (uint32_t)w) * S.E + e] = ln.m[k][w];
+                if (WT == 1 || ln.m[k][w] != m0[k][w]) S.put(k, (uint32_t)w, e, ln.m[k][w]);
         }
     }
     if (valid_out) valid_out[e] = ok ? 1 : 0;
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void defender_obs_kernel(DevState S, Topo T, i
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= S.E * S.N) return;
     const uint32_t e = g / S.N, n = g - e * S.N;
-    if (infected) infected[g] = (int8_t)((S.mask(M_INST)[(size_t)(n >> 6) * S.E + e] >> (n & 63u)) & 1ull);
+    if (infected) infected[g] = (int8_t)S.has(M_INST, n, e);
     const uint16_t* fw = reinterpret_cast<const uint16_t*>(S.body + (size_t)e * S.body_stride + S.off_fw);
     const uint32_t lists = reinterpret_cast<const mcbs_node_static*>(T.base + T.H().off_node)[n].fw_lists;
     const uint32_t fin = fw[lists & 0xFFFFu], fout = fw[lists >> 16];

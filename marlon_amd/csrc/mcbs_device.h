@@ -65,12 +65,26 @@ struct DevState {
     uint32_t* episode;  // [E]
     double*   pending;  // [E] raw reward carried between the split phases of mcbs_step_observe
     uint64_t* masks;    // [M_COUNT][WT][E]: discovered / agent installed / ever owned / running / privilege bit 0 / bit 1 /
-                        // gathered credential strings / cached credential triples; every set padded to WT words
-    __host__ __device__ __forceinline__ uint64_t* mask(int k) const { return masks + (size_t)k * WT * E; }
+                        // gathered credential strings / cached credential triples; every set padded to WT words.
+                        // `packed` batches (<= 16 nodes, credential strings and triples: Chain-10, ToyCtf): [E][M_COUNT] u16
+                        // instead, i.e. ONE 16-byte word per env holds all eight sets (a quarter of the bytes the step moves)
+    // word w of set k of env e, whichever layout the batch uses (kernels off the hot path; the step kernel is specialised)
+    __host__ __device__ __forceinline__ uint64_t set_word(const void* base, int k, uint32_t w, uint32_t e) const {
+        return packed ? (uint64_t)static_cast<const uint16_t*>(base)[(size_t)e * M_COUNT + (uint32_t)k]
+                      : static_cast<const uint64_t*>(base)[((size_t)k * WT + w) * E + e];
+    }
+    __host__ __device__ __forceinline__ void put_word(void* base, int k, uint32_t w, uint32_t e, uint64_t v) const {
+        if (packed) static_cast<uint16_t*>(base)[(size_t)e * M_COUNT + (uint32_t)k] = (uint16_t)v;
+        else static_cast<uint64_t*>(base)[((size_t)k * WT + w) * E + e] = v;
+    }
+    __device__ __forceinline__ uint64_t get(int k, uint32_t w, uint32_t e) const { return set_word(masks, k, w, e); }
+    __device__ __forceinline__ void put(int k, uint32_t w, uint32_t e, uint64_t v) const { put_word(masks, k, w, e, v); }
+    __device__ __forceinline__ bool has(int k, uint32_t n, uint32_t e) const { return (get(k, n >> 6, e) >> (n & 63u)) & 1ull; }
     uint64_t* ring;     // [16][NW][E] nodes being re-imaged, by the defender tick (mod 16) that releases them; null without defender
     uint8_t*  body;     // [E][body_stride]
     const uint8_t* init_body; // [body_stride] image of a freshly reset env
     uint32_t E, N, NW, SW, TW, WT;  // WT = words per set = max(NW, SW, TW) rounded to 1, 2 or 4
+    uint32_t packed;    // 1: the sets of an env are 16-bit fields of one uint4 (see masks)
     uint32_t body_stride, off_disc, off_cred, off_rows, Cmax;
     uint32_t off_fw;    // body offset of uint16 fw[n_fw_lists]: per-env state of the six manageable rule names in every firewall
                         // rule list (bit r: a rule named r exists, bit 6+r: the first one is ALLOW); MCBS_DEFENDER_EXTERNAL only
@@ -158,14 +172,13 @@ __device__ __forceinline__ void reset_header(const DevState& S, const Topo& T, u
             if (ns[n].priv0 & 2u) hi |= bit;
         }
         const uint32_t rem = S.N - w * 64u;
-        const size_t k = (size_t)w * S.E + e;
-        S.mask(M_DISC)[k] = m; S.mask(M_INST)[k] = m; S.mask(M_EVER)[k] = m; S.mask(M_PLO)[k] = lo; S.mask(M_PHI)[k] = hi;
-        S.mask(M_RUN)[k] = rem >= 64u ? ~0ull : ((1ull << rem) - 1ull);
+        S.put(M_DISC, w, e, m); S.put(M_INST, w, e, m); S.put(M_EVER, w, e, m); S.put(M_PLO, w, e, lo); S.put(M_PHI, w, e, hi);
+        S.put(M_RUN, w, e, rem >= 64u ? ~0ull : ((1ull << rem) - 1ull));
         if (S.ring) for (uint32_t s = 0; s < 16u; ++s) S.ring[((size_t)s * S.WT + w) * S.E + e] = 0;
     }
-    for (uint32_t w = 0; w < S.WT; ++w) { S.mask(M_GATH)[(size_t)w * S.E + e] = 0; S.mask(M_CACH)[(size_t)w * S.E + e] = 0; }
+    for (uint32_t w = 0; w < S.WT; ++w) { S.put(M_GATH, w, e, 0ull); S.put(M_CACH, w, e, 0ull); }
     for (uint32_t w = S.NW; w < S.WT; ++w)
-        for (int k = 0; k < M_GATH; ++k) S.mask(k)[(size_t)w * S.E + e] = 0;
+        for (int k = 0; k < M_GATH; ++k) S.put(k, w, e, 0ull);
     S.h0[e] = make_uint4(0u, 0u, n_init, n_init);
     S.h1[e] = make_double2(0.0, 1.0);
     S.episode[e] = episode;

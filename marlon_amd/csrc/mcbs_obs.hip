@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void obs_small_kernel(DevState S, Topo T, Step
             if (i < n_disc) {
                 const uint32_t n = dl[i];
                 ext_of[n] = (uint8_t)i;
-                own = (S.mask(M_INST)[(size_t)(n >> 6) * S.E + e] >> (n & 63u)) & 1ull;
+                own = S.has(M_INST, n, e);
             }
             own_ext[c] = __ballot(own);
         }
@@ -125,8 +125,7 @@ __global__ __launch_bounds__(256) void obs_small_kernel(DevState S, Topo T, Step
             int32_t v = 0;
             if (!blank && i < n_disc) {
                 const uint32_t n = dl[i];
-                const size_t k = (size_t)(n >> 6) * S.E + e;
-                v = (int32_t)(((S.mask(M_PLO)[k] >> (n & 63u)) & 1ull) | (((S.mask(M_PHI)[k] >> (n & 63u)) & 1ull) << 1));
+                v = (int32_t)((uint32_t)S.has(M_PLO, n, e) | ((uint32_t)S.has(M_PHI, n, e) << 1));
             }
             out[i] = v;
         }

@@ -326,8 +326,10 @@ struct Lane {
 // PHASE 2: defender, goals, outputs, auto-reset (after the observation kernels ran).
 // WT: words per set held in registers (1, 2 or 4; >= NW, SW, TW).  TOPO_LDS: topology tables staged in LDS.
 // DEFK: MCBS_DEFENDER_* (none / in-env ScanAndReimage / external learned defender).
-template <int PHASE, int WT, bool TOPO_LDS, int DEFK>
+template <int PHASE, int WTP, bool TOPO_LDS, int DEFK>
 __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, const StepCfg* __restrict__ Cp, StepIO io) {
+    constexpr bool PK = WTP == 0;           // packed batch: the eight sets are 16-bit fields of one uint4 per env
+    constexpr int WT = PK ? 1 : WTP;
     const StepCfg& C = *Cp;   // in device memory: fields are fetched by scalar loads where they are used, not all up front
     extern __shared__ uint4 topo_lds[];
 #ifdef MCBS_DIAG
@@ -360,11 +362,18 @@ __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, const Ste
         chead1 = *reinterpret_cast<const uint4*>(body + S.off_cred + 16);
     }
     uint64_t m0[M_COUNT][WT];        // every set is stored padded to WT words: no bounds to test, all loads independent
+    if (PK) {
+        const uint4 pk = reinterpret_cast<const uint4*>(S.masks)[ec];
+        const uint32_t f[4] = {pk.x, pk.y, pk.z, pk.w};
 #pragma unroll
-    for (int k = 0; k < M_COUNT; ++k) {
-        const bool wanted = PHASE != 2 || (k != M_GATH && k != M_CACH && k != M_DISC && k != M_EVER);
+        for (int k = 0; k < M_COUNT; ++k) m0[k][0] = (f[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
+    } else {
 #pragma unroll
-        for (int w = 0; w < WT; ++w) m0[k][w] = wanted ? S.masks[((uint32_t)k * WT + (uint32_t)w) * S.E + ec] : 0ull;
+        for (int k = 0; k < M_COUNT; ++k) {
+            const bool wanted = PHASE != 2 || (k != M_GATH && k != M_CACH && k != M_DISC && k != M_EVER);
+#pragma unroll
+            for (int w = 0; w < WT; ++w) m0[k][w] = wanted ? S.masks[((uint32_t)k * WT + (uint32_t)w) * S.E + ec] : 0ull;
+        }
     }
     double2 h1 = make_double2(0.0, 0.0);
     uint32_t episode = 0;
@@ -502,14 +511,23 @@ __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, const Ste
     {
         // sets the phase can have changed go back whole (WT == 1: one coalesced 8-byte store per set beats a compare and a
         // branch); an env about to be reset gets its columns rewritten below, after these stores in program order
+        if (PK) {
+            if (PHASE != 2 || has_def) {
+                uint32_t f[4];
 #pragma unroll
-        for (int k = 0; k < M_COUNT; ++k) {
-            const bool attacker_set = k != M_RUN;
-            const bool defender_set = k == M_RUN || k == M_INST || k == M_PLO || k == M_PHI;
-            if (!((PHASE != 2 && attacker_set) || (PHASE != 1 && has_def && defender_set))) continue;
+                for (int q = 0; q < 4; ++q) f[q] = (uint32_t)ln.m[2 * q][0] | ((uint32_t)ln.m[2 * q + 1][0] << 16);
+                reinterpret_cast<uint4*>(S.masks)[e] = make_uint4(f[0], f[1], f[2], f[3]);
+            }
+        } else {
 #pragma unroll
-            for (int w = 0; w < WT; ++w)
-                if (WT == 1 || ln.m[k][w] != m0[k][w]) S.masks[((uint32_t)k * WT + (uint32_t)w) * S.E + e] = ln.m[k][w];
+            for (int k = 0; k < M_COUNT; ++k) {
+                const bool attacker_set = k != M_RUN;
+                const bool defender_set = k == M_RUN || k == M_INST || k == M_PLO || k == M_PHI;
+                if (!((PHASE != 2 && attacker_set) || (PHASE != 1 && has_def && defender_set))) continue;
+#pragma unroll
+                for (int w = 0; w < WT; ++w)
+                    if (WT == 1 || ln.m[k][w] != m0[k][w]) S.masks[((uint32_t)k * WT + (uint32_t)w) * S.E + e] = ln.m[k][w];
+            }
         }
     }
     }

@@ -42,7 +42,7 @@ def load_library(path: Optional[str] = None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("MCBS_LIBRARY") or LIB_PATH      # MCBS_LIBRARY: developer override (e.g. the -DMCBS_DIAG build)
     if not os.path.exists(p):
         raise NativeLibraryMissing(
             f"{p} not found: the HIP extension has not been built. Build it with `make -C marlon_amd/csrc` "
