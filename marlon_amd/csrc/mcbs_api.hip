@@ -257,8 +257,14 @@ extern "C" int mcbs_batch_create(const mcbs_topology* topo, const mcbs_batch_cfg
     S.off_cred = (uint32_t)align_up((size_t)N + 1, 16);                         // u16 credential cache, >= 32 bytes
     S.off_rows = (uint32_t)align_up((size_t)S.off_cred + (2u * (h->n_triples + 1u) > 32u ? 2u * (h->n_triples + 1u) : 32u), 16);
     const bool external = cfg->defender_kind == MCBS_DEFENDER_EXTERNAL;
-    S.off_fw = external ? (uint32_t)align_up((size_t)S.off_rows + sizeof(Row) * N, 16) : 0u;
-    S.body_stride = (uint32_t)align_up(external ? (size_t)S.off_fw + 2u * h->n_fw_lists : (size_t)S.off_rows + sizeof(Row) * N, 64);
+    // small topologies (Chain-10, ToyCtf): the eight sets of an env as 16-bit fields of one 16-byte word and 4-byte node rows,
+    // so that the header and the WHOLE body are level-1 loads (mcbs_device.h); lists stay u8 / u16 with < 16 entries each
+    S.tiny_p = h->n_props; S.tiny_v = h->max_slots;
+    S.packed = (N <= 16u && h->n_cred_strings <= 16u && h->n_triples < 16u && S.tiny_p + 4u + 2u * S.tiny_v <= 32u &&
+                !getenv("MCBS_NO_PACKED_SETS")) ? 1u : 0u;
+    const size_t row_bytes = S.packed ? 4u : sizeof(Row);
+    S.off_fw = external ? (uint32_t)align_up((size_t)S.off_rows + row_bytes * N, 16) : 0u;
+    S.body_stride = (uint32_t)align_up(external ? (size_t)S.off_fw + 2u * h->n_fw_lists : (size_t)S.off_rows + row_bytes * N, S.packed ? 16 : 64);
 
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
@@ -266,14 +272,12 @@ extern "C" int mcbs_batch_create(const mcbs_topology* topo, const mcbs_batch_cfg
     uint32_t wt = S.NW > S.SW ? S.NW : S.SW;
     if (S.TW > wt) wt = S.TW;
     S.WT = wt <= 1 ? 1 : (wt == 2 ? 2 : 4);
-    // small topologies: the eight sets of an env as 16-bit fields of one 16-byte word (mcbs_device.h)
-    S.packed = (N <= 16u && h->n_cred_strings <= 16u && h->n_triples <= 16u && !getenv("MCBS_NO_PACKED_SETS")) ? 1u : 0u;
     const size_t o_masks = take(S.packed ? 16ull * E : 8ull * M_COUNT * S.WT * E);
     const bool has_def = cfg->defender_kind != MCBS_DEFENDER_NONE;   // in-env or external: both re-image nodes
     const size_t o_ring = has_def ? take(8ull * 16 * S.WT * E) : 0;
     const size_t o_init = take(S.body_stride);
     const size_t o_digest = take(sizeof(ObsDigest) * (size_t)E);
-    const size_t o_body = take((size_t)S.body_stride * E);
+    const size_t o_body = take((size_t)S.body_stride * E + 64);   // + 64: packed batches fetch a fixed 64 bytes of rows per env
     b->arena_bytes = off;
 
     hipError_t e = hipSetDevice(cfg->device);
@@ -297,7 +301,7 @@ extern "C" int mcbs_batch_create(const mcbs_topology* topo, const mcbs_batch_cfg
         Row r{};
         const bool owned0 = (ns[n].flags & MCBS_NODE_INSTALLED0) != 0;
         r.props_tags = (owned0 ? ns[n].props : 0ull) | ((uint64_t)(ns[n].tags0 & 0xFu) << 60);
-        memcpy(init.data() + S.off_rows + sizeof(Row) * n, &r, sizeof(r));
+        S.row_put(init.data(), n, r);
     }
     memcpy(init.data() + S.off_disc, topo->host.data() + h->off_init_order, h->n_init_owned);
     if (external) memcpy(init.data() + S.off_fw, topo->host.data() + h->off_fw_list0, 2u * h->n_fw_lists);
@@ -621,8 +625,7 @@ extern "C" int mcbs_get_state(mcbs_batch* b, void* host_buf, size_t nbytes) {
         mcbs_state_node* sn = reinterpret_cast<mcbs_state_node*>(p + sizeof(mcbs_state_header));
         const uint8_t* eb = body + (size_t)e * S.body_stride;
         for (uint32_t n = 0; n < S.N; ++n) {
-            Row r;
-            memcpy(&r, eb + S.off_rows + sizeof(Row) * n, sizeof(r));
+            const Row r = S.row_get(eb, n);
             const uint64_t bit = 1ull << (n & 63u);
             sn[n].discovered_props = r.props_tags & ROW_PROPS_MASK; sn[n].attacked_ever = r.ever; sn[n].attacked_since = r.since;
             sn[n].discovered = has(M_DISC, n, e); sn[n].installed = has(M_INST, n, e);
@@ -692,7 +695,7 @@ extern "C" int mcbs_set_state(mcbs_batch* b, const void* host_buf, size_t nbytes
             Row r{};
             r.props_tags = (sn[n].discovered_props & ROW_PROPS_MASK) | ((uint64_t)(sn[n].tags & 0xFu) << 60);
             r.ever = sn[n].attacked_ever; r.since = sn[n].attacked_since;
-            memcpy(eb + S.off_rows + sizeof(Row) * n, &r, sizeof(r));
+            S.row_put(eb, n, r);
         }
         for (uint32_t i = 0; i < sh->n_discovered; ++i) {
             if (order[i] >= S.N) return fail(MCBS_EINVAL, "env %u: discovery order entry out of range", e);

@@ -84,7 +84,29 @@ struct DevState {
     uint8_t*  body;     // [E][body_stride]
     const uint8_t* init_body; // [body_stride] image of a freshly reset env
     uint32_t E, N, NW, SW, TW, WT;  // WT = words per set = max(NW, SW, TW) rounded to 1, 2 or 4
-    uint32_t packed;    // 1: the sets of an env are 16-bit fields of one uint4 (see masks)
+    uint32_t packed;    // 1: the sets of an env are 16-bit fields of one uint4 (see masks) and its node rows are 4 bytes each:
+    uint32_t tiny_p, tiny_v;   // properties (tiny_p bits) | tags (4) | attacked-ever (tiny_v bits) | attacked-since (tiny_v bits) <= 32 bits,
+                        // so that the whole body (discovery order 16 B, credential cache 32 B, <= 16 rows 64 B) is fetched with the header
+                        // and the step has no load that depends on the action (Chain-10: 14 + 4 + 7 + 7 = 32 bits)
+    __host__ __device__ __forceinline__ uint32_t tiny_pack(uint64_t props, uint32_t tags, uint32_t ever, uint32_t since) const {
+        return (uint32_t)props | (tags << tiny_p) | (ever << (tiny_p + 4u)) | (tiny_v ? since << (tiny_p + 4u + tiny_v) : 0u);
+    }
+    // row n of the env whose body starts at body_e, in the canonical 16-byte form, whichever layout the batch uses
+    __host__ __device__ __forceinline__ Row row_get(const uint8_t* body_e, uint32_t n) const {
+        if (!packed) return reinterpret_cast<const Row*>(body_e + off_rows)[n];
+        const uint32_t w = reinterpret_cast<const uint32_t*>(body_e + off_rows)[n], vm = (1u << tiny_v) - 1u;
+        Row r;
+        r.props_tags = (uint64_t)(w & ((1u << tiny_p) - 1u)) | ((uint64_t)((w >> tiny_p) & 0xFu) << 60);
+        r.ever = (w >> (tiny_p + 4u)) & vm;
+        r.since = tiny_v ? (w >> (tiny_p + 4u + tiny_v)) & vm : 0u;
+        return r;
+    }
+    __host__ __device__ __forceinline__ void row_put(uint8_t* body_e, uint32_t n, const Row& r) const {
+        if (!packed) { reinterpret_cast<Row*>(body_e + off_rows)[n] = r; return; }
+        reinterpret_cast<uint32_t*>(body_e + off_rows)[n] =
+            tiny_pack(r.props_tags & ((1ull << tiny_p) - 1ull), (uint32_t)(r.props_tags >> 60), r.ever & ((1u << tiny_v) - 1u),
+                      r.since & ((1u << tiny_v) - 1u));
+    }
     uint32_t body_stride, off_disc, off_cred, off_rows, Cmax;
     uint32_t off_fw;    // body offset of uint16 fw[n_fw_lists]: per-env state of the six manageable rule names in every firewall
                         // rule list (bit r: a rule named r exists, bit 6+r: the first one is ALLOW); MCBS_DEFENDER_EXTERNAL only

@@ -39,7 +39,6 @@ __global__ __launch_bounds__(256) void obs_small_kernel(DevState S, Topo T, Step
     const uint32_t kind = (flags >> F_KIND_SHIFT) & 0xFu, level = (flags >> F_LEVEL_SHIFT) & 3u;
     const uint32_t new_nodes = (flags >> F_NEWNODES_SHIFT) & 0x3FFu, new_creds = (flags >> F_NEWCREDS_SHIFT) & 0x3FFu;
     const uint8_t* body = S.body + (size_t)e * S.body_stride;
-    const Row* rows = reinterpret_cast<const Row*>(body + S.off_rows);
     const uint8_t* dl = body + S.off_disc;
     const uint16_t* cl = reinterpret_cast<const uint16_t*>(body + S.off_cred);
     const mcbs_node_static* NS = reinterpret_cast<const mcbs_node_static*>(T.base + C.off_node);
@@ -115,7 +114,7 @@ __global__ __launch_bounds__(256) void obs_small_kernel(DevState S, Topo T, Step
         int32_t* out = O.props + (size_t)e * Nm * NP;
         for (uint32_t i = 0; i < Nm; ++i) {   // one discovered node per iteration, lanes over properties
             uint64_t pm = 0;
-            if (!blank && i < n_disc) pm = rows[dl[i]].props_tags & ROW_PROPS_MASK;
+            if (!blank && i < n_disc) pm = S.row_get(body, dl[i]).props_tags & ROW_PROPS_MASK;
             for (uint32_t p = lane; p < NP; p += 64u) out[i * NP + p] = blank ? 2 : (int32_t)((pm >> p) & 1ull);
         }
     }

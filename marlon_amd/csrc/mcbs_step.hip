@@ -100,6 +100,18 @@ __device__ __forceinline__ uint32_t half_of(const uint4& a, const uint4& b, uint
     return (uint32_t)(((i & 8u) ? wb : wa) >> ((i & 3u) * 16u)) & 0xFFFFu;
 }
 
+// dword i (< 16) of four 16-byte vectors, as 64-bit selects and one shift (see byte_of)
+__device__ __forceinline__ uint32_t dword_of(const uint4& r0, const uint4& r1, const uint4& r2, const uint4& r3, uint32_t i) {
+#define MCBS_P64(a, b) ((uint64_t)(a) | ((uint64_t)(b) << 32))
+    const uint64_t p0 = MCBS_P64(r0.x, r0.y), p1 = MCBS_P64(r0.z, r0.w), p2 = MCBS_P64(r1.x, r1.y), p3 = MCBS_P64(r1.z, r1.w);
+    const uint64_t p4 = MCBS_P64(r2.x, r2.y), p5 = MCBS_P64(r2.z, r2.w), p6 = MCBS_P64(r3.x, r3.y), p7 = MCBS_P64(r3.z, r3.w);
+#undef MCBS_P64
+    const bool b1 = i & 2u, b2 = i & 4u, b3 = i & 8u;
+    const uint64_t q0 = b1 ? p1 : p0, q1 = b1 ? p3 : p2, q2 = b1 ? p5 : p4, q3 = b1 ? p7 : p6;
+    const uint64_t s0 = b2 ? q1 : q0, s1 = b2 ? q3 : q2;
+    return (uint32_t)((b3 ? s1 : s0) >> ((i & 1u) * 32u));
+}
+
 // ------------------------------ per-lane working set ------------------------------
 template <int WT>
 struct Lane {
@@ -313,7 +325,8 @@ struct Lane {
     // reimage_node (actions.py:700-712): agent removed, privilege NoAccess, Imaging for REIMAGING_DURATION ticks; tags,
     // discovered properties and credentials stay (quirk Q6)
     __device__ __forceinline__ void reimage(uint32_t n, uint64_t (&fresh)[WT]) {
-        row(n)->since = 0;                                    // every earlier attack now predates last_reimaging
+        if (S.packed) reinterpret_cast<uint32_t*>(body + S.off_rows)[n] &= (1u << (S.tiny_p + 4u + S.tiny_v)) - 1u;
+        else row(n)->since = 0;                               // every earlier attack now predates last_reimaging
         rclear<WT>(m[M_INST], n);
         if (privilege(n)) { set_privilege(n, 0u); owned -= 1; }
         rclear<WT>(m[M_RUN], n);
@@ -360,6 +373,12 @@ __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, const Ste
         dhead = *reinterpret_cast<const uint4*>(body + S.off_disc);
         chead0 = *reinterpret_cast<const uint4*>(body + S.off_cred);
         chead1 = *reinterpret_cast<const uint4*>(body + S.off_cred + 16);
+    }
+    uint4 rw0 = make_uint4(0, 0, 0, 0), rw1 = rw0, rw2 = rw0, rw3 = rw0;
+    if (PK && PHASE != 2) {                              // packed batch: every 4-byte node row of the env (<= 64 bytes)
+        const uint4* rp = reinterpret_cast<const uint4*>(body + S.off_rows);
+        rw0 = rp[0]; rw1 = rp[1]; rw2 = rp[2];
+        if (S.N > 12u) rw3 = rp[3];
     }
     uint64_t m0[M_COUNT][WT];        // every set is stored padded to WT words: no bounds to test, all loads independent
     if (PK) {
@@ -435,8 +454,13 @@ __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, const Ste
             const uint32_t s2 = ln.disc_list()[i1], t2 = ln.disc_list()[i2], c2 = ln.cred_list()[i4];
             src = i1 >= 16u ? s2 : src; tgt = i2 >= 16u ? t2 : tgt; triple = i4 >= 16u ? c2 : triple;
         }
-        // ---------------- level 2: the target row ----------------
-        const uint4 r0 = *reinterpret_cast<const uint4*>(ln.row(tgt));
+        // ---------------- level 2: the target row (packed batches: already here) ----------------
+        uint4 r0;
+        if (PK) {
+            const uint32_t w = dword_of(rw0, rw1, rw2, rw3, tgt), vm = (1u << S.tiny_v) - 1u;
+            r0 = make_uint4(w & ((1u << S.tiny_p) - 1u), ((w >> S.tiny_p) & 0xFu) << 28, (w >> (S.tiny_p + 4u)) & vm,
+                            (w >> (S.tiny_p + 4u + S.tiny_v)) & vm);
+        } else r0 = *reinterpret_cast<const uint4*>(ln.row(tgt));
         if (learned) {
             const uint16_t* fw = reinterpret_cast<const uint16_t*>(body + S.off_fw);
             const uint32_t* lists = reinterpret_cast<const uint32_t*>(tb + C.hot_fwlist);
@@ -447,8 +471,12 @@ __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, const Ste
         ln.ever = r0.z; ln.since = r0.w;
         STAMP(3);  // row landed
         ln.act(X, skip ? -1.0 : 0.0, kind, src, tgt, X ? (k0 ? a2 : (k1 ? C.L + a3 : 0u)) : 0u, (X & k2) ? a3 : 0u, triple);
-        const uint64_t wpt = ln.props | ((uint64_t)ln.tags << 60);   // unchanged rows are written back as they were
-        *reinterpret_cast<uint4*>(ln.row(tgt)) = make_uint4((uint32_t)wpt, (uint32_t)(wpt >> 32), ln.ever, ln.since);
+        // unchanged rows are written back as they were
+        if (PK) reinterpret_cast<uint32_t*>(body + S.off_rows)[tgt] = S.tiny_pack(ln.props, ln.tags, ln.ever, ln.since);
+        else {
+            const uint64_t wpt = ln.props | ((uint64_t)ln.tags << 60);
+            *reinterpret_cast<uint4*>(ln.row(tgt)) = make_uint4((uint32_t)wpt, (uint32_t)(wpt >> 32), ln.ever, ln.since);
+        }
         STAMP(4);      // attacker logic and row store done
         const uint32_t nf = (oob ? F_OOB : 0u) | ((uint32_t)ln.okind << F_KIND_SHIFT) | ((uint32_t)ln.olevel << F_LEVEL_SHIFT) |
                             ((uint32_t)ln.new_nodes << F_NEWNODES_SHIFT) | ((uint32_t)ln.new_creds << F_NEWCREDS_SHIFT);
