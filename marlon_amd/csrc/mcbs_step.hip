@@ -354,6 +354,10 @@ __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, const Ste
 #define STAMP_NOWAIT(i)
 #endif
     STAMP_NOWAIT(0);
+    // action-space bounds as scalars, fetched now: left alone, the compiler turns `k1 ? C.R : C.P` into a per-lane VECTOR load
+    // from the config (select of two loads -> load of the selected address), i.e. one more memory round trip after level 1
+    uint32_t cL = C.L, cR = C.R, cP = C.P;
+    asm volatile("" : "+s"(cL), "+s"(cR), "+s"(cP));
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = e < S.E;
     const uint32_t ec = active ? e : 0u;                // clamp so inactive lanes read valid memory and take no branch
@@ -443,14 +447,14 @@ __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, const Ste
         const bool k0 = kind == 0, k1 = kind == 1, k2 = kind == 2;
         const bool skip = k2 & (a4 >= ln.n_creds);              // connect with a credential index outside the cache: env.py:736-737,
                                                                 // before any node look-up
-        const bool bad = (a1 >= ln.n_disc) | (a2 >= (k0 ? C.L : ln.n_disc)) | (!k0 & (a3 >= (k1 ? C.R : C.P)));
+        const bool bad = (a1 >= ln.n_disc) | (a2 >= (k0 ? cL : ln.n_disc)) | (!k0 & (a3 >= (k1 ? cR : cP)));
         oob = live & (!(k0 | k1 | k2) | (!skip & bad));
         const bool X = live & !skip & !oob & (k0 | k1 | k2);
         // indices every lane may use: its own when the action executes, entry 0 otherwise
         const uint32_t i1 = X ? a1 : 0u, i2 = (X & !k0) ? a2 : i1, i4 = (X & k2) ? a4 : 0u;
         uint32_t src = byte_of(dhead, i1 & 15u), tgt = byte_of(dhead, i2 & 15u);
         uint32_t triple = half_of(chead0, chead1, i4 & 15u);
-        if ((i1 | i2 | i4) >= 16u) {                            // large topologies: entries past the first 16 of a list
+        if (!PK && (i1 | i2 | i4) >= 16u) {                     // large topologies: entries past the first 16 of a list
             const uint32_t s2 = ln.disc_list()[i1], t2 = ln.disc_list()[i2], c2 = ln.cred_list()[i4];
             src = i1 >= 16u ? s2 : src; tgt = i2 >= 16u ? t2 : tgt; triple = i4 >= 16u ? c2 : triple;
         }
@@ -470,7 +474,7 @@ __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, const Ste
         ln.props = pt & ROW_PROPS_MASK; ln.tags = (uint32_t)(pt >> 60);
         ln.ever = r0.z; ln.since = r0.w;
         STAMP(3);  // row landed
-        ln.act(X, skip ? -1.0 : 0.0, kind, src, tgt, X ? (k0 ? a2 : (k1 ? C.L + a3 : 0u)) : 0u, (X & k2) ? a3 : 0u, triple);
+        ln.act(X, skip ? -1.0 : 0.0, kind, src, tgt, X ? (k0 ? a2 : (k1 ? cL + a3 : 0u)) : 0u, (X & k2) ? a3 : 0u, triple);
         // unchanged rows are written back as they were
         if (PK) reinterpret_cast<uint32_t*>(body + S.off_rows)[tgt] = S.tiny_pack(ln.props, ln.tags, ln.ever, ln.since);
         else {
