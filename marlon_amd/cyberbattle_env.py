@@ -337,3 +337,38 @@ class CyberBattleToyCtf(CyberBattleEnv):
 
     def __init__(self, **kwargs):
         super().__init__(initial_environment=toy_ctf.new_environment(), **kwargs)
+
+
+class CyberBattleTiny(CyberBattleEnv):
+    """_env/cyberbattle_tiny.py:8-12 (`CyberBattleTiny-v0`)"""
+
+    def __init__(self, **kwargs):
+        from .samples import tinytoy
+        super().__init__(initial_environment=tinytoy.new_environment(), **kwargs)
+
+
+class CyberBattleRandom(CyberBattleEnv):
+    """_env/cyberbattle_random.py:10-14 (`CyberBattleRandom-v0`): a freshly generated 50-client / 3 x 15-server traffic
+    network with up to 32 credentials per leak.  `seed` (not in the reference, whose networks are unrepeatable) makes the
+    generated network reproducible; further keyword arguments go to CyberBattleEnv."""
+
+    def __init__(self, seed=None, **kwargs):
+        from .samples import generate_network
+        kwargs.setdefault("maximum_discoverable_credentials_per_action", 32)
+        super().__init__(initial_environment=generate_network.new_environment(n_servers_per_protocol=15, seed=seed), **kwargs)
+
+
+class CyberBattleActiveDirectory(CyberBattleEnv):
+    """_env/active_directory.py:6-10 (`ActiveDirectory-v{seed}`)"""
+
+    def __init__(self, seed, **kwargs):
+        from .samples import active_directory
+        super().__init__(initial_environment=active_directory.new_random_environment(seed), **kwargs)
+
+
+class CyberBattleActiveDirectoryTiny(CyberBattleEnv):
+    """_env/active_directory.py:13-15 (`ActiveDirectoryTiny-v0`)"""
+
+    def __init__(self, **kwargs):
+        from .samples import active_directory
+        super().__init__(initial_environment=active_directory.new_tiny_environment(), **kwargs)

@@ -12,7 +12,7 @@ import numpy as np
 from marlon_amd import flatten as F
 from marlon_amd import model
 from marlon_amd._abi import RNG_TAPE, EnvSpec
-from marlon_amd.samples import chainpattern, kitchen_sink, random_net, toy_ctf
+from marlon_amd.samples import active_directory, chainpattern, generate_network, kitchen_sink, random_net, tinytoy, toy_ctf
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 OBS_FIELDS = ["scalars", "leaked_credentials", "credential_cache_matrix", "discovered_nodes_properties",
@@ -33,6 +33,14 @@ def topology_for(trace_name: str) -> F.FlatTopology:
         return F.flatten(kitchen_sink.build(model, entry_reimagable=True))
     if trace_name.startswith("sink"):
         return F.flatten(kitchen_sink.build(model))
+    if trace_name.startswith("tinyad"):
+        return F.flatten(active_directory.new_tiny_environment())
+    if trace_name.startswith("tiny"):
+        return F.flatten(tinytoy.new_environment())
+    if trace_name.startswith("ad0") or trace_name.startswith("ad2"):
+        return F.flatten(active_directory.new_random_environment(int(trace_name[2])))
+    if trace_name.startswith("random_s"):
+        return F.flatten(generate_network.new_environment(15, seed=int(trace_name.split("_")[1][1:])))
     if trace_name.startswith("random24"):
         return F.flatten(random_net.build(model, 24, 7))
     raise KeyError(trace_name)

@@ -10,7 +10,7 @@ import pytest
 
 from marlon_amd import flatten as F
 from marlon_amd import model as m
-from marlon_amd.samples import chainpattern, kitchen_sink, random_net, toy_ctf
+from marlon_amd.samples import active_directory, chainpattern, generate_network, kitchen_sink, random_net, tinytoy, toy_ctf
 
 CASES = {
     "chain4": lambda: chainpattern.new_environment(4),
@@ -20,6 +20,16 @@ CASES = {
     "sink": kitchen_sink.new_environment,
     "sink_evict": lambda: kitchen_sink.build(m, entry_reimagable=True),
     "random24": lambda: random_net.build(m, 24, 7),
+    # the other registered environments (fixtures: oracle/refharness/gen_golden_envs.py); the seeded generators must consume
+    # Python's `random`, numpy's legacy global state and networkx's block model exactly as the reference does
+    "tiny": tinytoy.new_environment,
+    "tinyad": active_directory.new_tiny_environment,
+    "ad0": lambda: active_directory.new_random_environment(0),
+    "ad2": lambda: active_directory.new_random_environment(2),
+    "random_s1": lambda: generate_network.new_environment(15, seed=1),
+    "random_s4": lambda: generate_network.new_environment(15, seed=4),
+    "random_s5": lambda: generate_network.new_environment(15, seed=5),
+    "random_s9": lambda: generate_network.new_environment(15, seed=9),
 }
 
 
@@ -123,3 +133,9 @@ def test_availability_terms_follow_reference_order():
     assert h["total_sla_weight"] == total and h["full_sum"] == full and h["full_availability"] == full / total
     assert h["avail_any_order"] == 0                                     # 0.3 * 2/3 is not dyadic
     assert F.flatten(toy_ctf.new_environment()).header()["avail_any_order"] == 1
+
+
+def test_active_directory_seeds_beyond_the_engine_limit_are_rejected_loudly():
+    """ActiveDirectory seeds whose DumpNTDS leaks more than 256 distinct credentials exceed this build's set width."""
+    with pytest.raises(ValueError, match="too many distinct credentials"):
+        F.flatten(active_directory.new_random_environment(1))
