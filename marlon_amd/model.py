@@ -18,6 +18,7 @@ Two reference quirks are kept on purpose:
 from __future__ import annotations
 
 import enum
+import random
 from collections import OrderedDict
 from dataclasses import dataclass, field
 from typing import Dict, Iterable, Iterator, List, NamedTuple, Optional, Tuple, Union
@@ -340,3 +341,64 @@ def infer_constants_from_nodes(nodes, vulnerabilities: VulnerabilityLibrary) -> 
 
 def infer_constants_from_network(network, vulnerabilities: VulnerabilityLibrary) -> Identifiers:
     return infer_constants_from_nodes(iterate_network_nodes(network), vulnerabilities)
+
+
+# -- random labelling of a graph (model.py:470-539) --
+
+SAMPLE_IDENTIFIERS = Identifiers(
+    ports=["RDP", "SSH", "SMB", "HTTP", "HTTPS", "WMI", "SQL"],
+    properties=["Windows", "Linux", "HyperV-VM", "Azure-VM", "Win7", "Win10", "PortRDPOpen", "GuestAccountEnabled"])
+
+
+def assign_random_labels(graph, vulnerabilities: VulnerabilityLibrary = {}, identifiers: Identifiers = SAMPLE_IDENTIFIERS) -> Network:
+    """Environment network over the nodes of `graph` (anything with `.nodes` and `.edges()`, e.g. a networkx.DiGraph) with
+    randomly drawn properties, firewall rules, a random subset of `vulnerabilities` and, for nodes with out-edges, a
+    `RecentlyAccessedMachines` vulnerability leaking their successors.
+
+    Consumes Python's `random` exactly as the reference does (model.py:475-539), so `random.seed(s)` beforehand yields its
+    network: the entry node's index; then per node — entry first, the others in graph order — [a value in 0..100, not for
+    the entry node], the number of properties and their sample, the library threshold and one draw per library entry, the
+    number of outgoing ports and their sample, the same for incoming.  The reference lists a node's successors through a
+    Python set of strings, whose order depends on the interpreter's hash seed when there are several; successors are listed in
+    edge order here (identical for nodes with at most one successor, and the step rules never depend on that order)."""
+    ids = [str(n) for n in graph.nodes]
+    edges = [(str(s), str(t)) for (s, t) in graph.edges()]
+
+    def properties() -> List[PropertyName]:
+        k = random.randint(0, len(identifiers.properties))
+        return list(random.sample(identifiers.properties, k=k))
+
+    def rules() -> List[FirewallRule]:
+        k = random.randint(0, len(identifiers.ports))
+        return [FirewallRule(port=p, permission=RulePermission.ALLOW) for p in random.sample(identifiers.ports, k=k)]
+
+    def firewall() -> FirewallConfiguration:
+        outgoing = rules()
+        return FirewallConfiguration(outgoing=outgoing, incoming=rules())
+
+    def library(node_id: NodeID) -> VulnerabilityLibrary:
+        threshold = random.random()
+        lib = {k: v for (k, v) in vulnerabilities.items() if random.random() > threshold}
+        successors = []
+        for (s, t) in edges:
+            if s == node_id and t not in successors:
+                successors.append(t)
+        if successors:
+            lib["RecentlyAccessedMachines"] = VulnerabilityInfo(description="AzureVM info, including public IP address",
+                                                                type=VulnerabilityType.LOCAL, outcome=LeakedNodesId(successors))
+        return lib
+
+    entry = ids[random.randrange(len(ids))]
+    data: Dict[NodeID, NodeInfo] = {}
+    p = properties()
+    v = library(entry)
+    data[entry] = NodeInfo(services=[], value=0, properties=p, vulnerabilities=v, firewall=firewall(), agent_installed=True,
+                           reimagable=False, privilege_level=PrivilegeLevel.Admin)
+    for node in ids:
+        if node != entry:
+            value = random.randint(0, 100)
+            p = properties()
+            v = library(node)
+            data[node] = NodeInfo(services=[], value=value, properties=p, vulnerabilities=v, firewall=firewall(),
+                                  agent_installed=False, privilege_level=PrivilegeLevel.NoAccess)
+    return create_network({n: data[n] for n in ids})

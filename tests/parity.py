@@ -12,7 +12,8 @@ import numpy as np
 from marlon_amd import flatten as F
 from marlon_amd import model
 from marlon_amd._abi import RNG_TAPE, EnvSpec
-from marlon_amd.samples import active_directory, chainpattern, generate_network, kitchen_sink, random_net, tinytoy, toy_ctf
+from marlon_amd.samples import (active_directory, chainpattern, generate_network, kitchen_sink, labelled_graph, random_net,
+                                tinytoy, toy_ctf)
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 OBS_FIELDS = ["scalars", "leaked_credentials", "credential_cache_matrix", "discovered_nodes_properties",
@@ -41,6 +42,8 @@ def topology_for(trace_name: str) -> F.FlatTopology:
         return F.flatten(active_directory.new_random_environment(int(trace_name[2])))
     if trace_name.startswith("random_s"):
         return F.flatten(generate_network.new_environment(15, seed=int(trace_name.split("_")[1][1:])))
+    if trace_name.startswith("labelled_s"):
+        return F.flatten(labelled_graph.build(model, int(trace_name.split("_")[1][1:]), 6))
     if trace_name.startswith("random24"):
         return F.flatten(random_net.build(model, 24, 7))
     raise KeyError(trace_name)

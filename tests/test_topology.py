@@ -10,7 +10,8 @@ import pytest
 
 from marlon_amd import flatten as F
 from marlon_amd import model as m
-from marlon_amd.samples import active_directory, chainpattern, generate_network, kitchen_sink, random_net, tinytoy, toy_ctf
+from marlon_amd.samples import (active_directory, chainpattern, generate_network, kitchen_sink, labelled_graph, random_net,
+                                tinytoy, toy_ctf)
 
 CASES = {
     "chain4": lambda: chainpattern.new_environment(4),
@@ -30,6 +31,7 @@ CASES = {
     "random_s4": lambda: generate_network.new_environment(15, seed=4),
     "random_s5": lambda: generate_network.new_environment(15, seed=5),
     "random_s9": lambda: generate_network.new_environment(15, seed=9),
+    "labelled_s4": lambda: labelled_graph.build(m, 4, 6),       # model.assign_random_labels
 }
 
 
