@@ -402,3 +402,66 @@ def assign_random_labels(graph, vulnerabilities: VulnerabilityLibrary = {}, iden
             data[node] = NodeInfo(services=[], value=value, properties=p, vulnerabilities=v, firewall=firewall(),
                                   agent_installed=False, privilege_level=PrivilegeLevel.NoAccess)
     return create_network({n: data[n] for n in ids})
+
+
+# -- reading an Environment from the reference's YAML (model.py:545-554, model_test.py:53-106) --
+
+def load_environment_yaml(stream) -> Environment:
+    """Read an environment written by the reference (`yaml.dump(env)` after `model.setup_yaml_serializer()`).
+
+    That format is PyYAML's python-object dialect (`!!python/object:cyberbattle.simulation.model.NodeInfo` ...), which the
+    reference reads back with the unsafe `yaml.Loader`.  Here the document is read with a SafeLoader that knows exactly
+    the tags of the simulation model and of the networkx graph wrapping the nodes and maps them onto THIS module's
+    classes: nothing is imported or called by name from the file.  Anchors / aliases are honoured, so rule lists and
+    credential lists shared between nodes stay shared objects (the firewall-list aliasing of DESIGN.md).  Edges of the graph
+    are dropped like everywhere else in this package; `creationTime` / `lastModified` are ignored."""
+    import yaml
+
+    prefix = "cyberbattle.simulation.model."
+    plain = {c.__name__: c for c in (ListeningService, FirewallRule, FirewallConfiguration, NodeInfo, LateralMove, CustomerData,
+                                     PrivilegeEscalation, SystemEscalation, AdminEscalation, ProbeSucceeded, ProbeFailed,
+                                     ExploitFailed, LeakedCredentials, LeakedNodesId)}
+    tuples = {c.__name__: c for c in (Rates, CachedCredential, VulnerabilityInfo, Identifiers)}
+    enums = {c.__name__: c for c in (RulePermission, PrivilegeLevel, MachineStatus, VulnerabilityType)}
+
+    class Loader(yaml.SafeLoader):
+        pass
+
+    def model_class(suffix, table, node):
+        if not suffix.startswith(prefix) or suffix[len(prefix):] not in table:
+            raise yaml.constructor.ConstructorError(None, None, f"tag {suffix!r} is not part of the environment format", node.start_mark)
+        return table[suffix[len(prefix):]]
+
+    def construct_object(loader, suffix, node):
+        if suffix == prefix + "Environment":
+            state = loader.construct_mapping(node, deep=True)
+            return Environment(network=state["network"], vulnerability_library=state.get("vulnerability_library", {}),
+                               identifiers=state["identifiers"], version=state.get("version", VERSION_TAG))
+        if suffix == "networkx.classes.digraph.DiGraph":
+            state = loader.construct_mapping(node, deep=True)
+            net = Network()
+            net.add_nodes_from((k, {"data": v["data"]}) for k, v in state["_node"].items())
+            return net
+        cls = model_class(suffix, plain, node)
+        obj = cls.__new__(cls)
+        state = loader.construct_mapping(node, deep=True) if isinstance(node, yaml.MappingNode) else {}
+        if isinstance(state.get("privilege_level"), int):
+            state["privilege_level"] = PrivilegeLevel(state["privilege_level"])
+        obj.__dict__.update(state)
+        return obj
+
+    def construct_new(loader, suffix, node):
+        return model_class(suffix, tuples, node)(*loader.construct_sequence(node, deep=True))
+
+    def construct_apply(loader, suffix, node):
+        return model_class(suffix, enums, node)(*loader.construct_sequence(node, deep=True))
+
+    Loader.add_multi_constructor("tag:yaml.org,2002:python/object:", construct_object)
+    Loader.add_multi_constructor("tag:yaml.org,2002:python/object/new:", construct_new)
+    Loader.add_multi_constructor("tag:yaml.org,2002:python/object/apply:", construct_apply)
+    Loader.add_constructor("!BooleanExpression", lambda loader, node: Precondition(loader.construct_scalar(node)))
+    Loader.add_constructor("!VulnerabilityType", lambda loader, node: VulnerabilityType[loader.construct_scalar(node)])
+    env = yaml.load(stream, Loader)
+    if not isinstance(env, Environment):
+        raise ValueError("the document is not a serialized Environment")
+    return env

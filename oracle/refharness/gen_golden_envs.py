@@ -65,6 +65,18 @@ def main():
                            credential_strings=t.credential_strings, triples=t.triples), f, indent=0)
         print(f"topology_{k}: {t.n_nodes} nodes, {len(t.triples)} triples, {len(t.blob)} bytes")
 
+    # ---- environments as the reference serialises them (model.py:545-554; yaml.dump sorts mappings, so the environment that
+    # yaml.load returns lists its nodes alphabetically): the text, and the blob of what the reference reads back from it ----
+    import yaml
+    from marlon_amd.samples import kitchen_sink
+    ref.model.setup_yaml_serializer()
+    for k, env in (("toyctf", ref.toy_ctf.new_environment()), ("sink", kitchen_sink.build(ref.model))):
+        text = yaml.dump(env)
+        with open(os.path.join(G.GOLDEN, f"env_{k}.yaml"), "w") as f:
+            f.write(text)
+        with open(os.path.join(G.GOLDEN, f"topology_yaml_{k}.bin"), "wb") as f:
+            f.write(F.flatten(yaml.load(text, yaml.Loader)).blob)
+
     def goal(**kw):
         g = dict(reward=0.0, low_availability=1.0, own_atleast=0, own_atleast_percent=1.0)
         g.update(kw)

@@ -141,3 +141,23 @@ def test_active_directory_seeds_beyond_the_engine_limit_are_rejected_loudly():
     """ActiveDirectory seeds whose DumpNTDS leaks more than 256 distinct credentials exceed this build's set width."""
     with pytest.raises(ValueError, match="too many distinct credentials"):
         F.flatten(active_directory.new_random_environment(1))
+
+
+@pytest.mark.parametrize("name", ["toyctf", "sink"])
+def test_yaml_environment_loads_like_the_reference(name, golden_dir):
+    """tests/golden/env_*.yaml is the reference's own `yaml.dump(env)`; topology_yaml_*.bin is the blob of what the
+    reference's `yaml.load(text, yaml.Loader)` makes of it (nodes in the file's, i.e. alphabetical, order)."""
+    with open(os.path.join(golden_dir, f"env_{name}.yaml")) as f:
+        env = m.load_environment_yaml(f)
+    with open(os.path.join(golden_dir, f"topology_yaml_{name}.bin"), "rb") as f:
+        assert F.flatten(env).blob == f.read()
+
+
+def test_yaml_loader_constructs_nothing_outside_the_model():
+    import yaml
+    for doc in ("!!python/object/apply:os.system ['true']", "!!python/object:subprocess.Popen {}",
+                "!!python/object/new:cyberbattle.simulation.model.Environment []", "!!python/name:os.system"):
+        with pytest.raises(yaml.YAMLError):
+            m.load_environment_yaml(doc)
+    with pytest.raises(ValueError):
+        m.load_environment_yaml("just: a mapping")
