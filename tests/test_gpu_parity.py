@@ -113,6 +113,41 @@ def test_engine_matches_oracle_batched(case, policy):
     eng.close()
 
 
+@pytest.mark.parametrize("trace", ["chain10_script", "toyctf_defender_s11"])
+def test_general_layout_equals_packed_layout(trace, monkeypatch):
+    """Small topologies run in the packed layout (16-bit sets, 4-byte rows); MCBS_NO_PACKED_SETS=1 (read at batch creation)
+    forces the general layout every larger topology uses.  Same actions, same Philox draws: every output, the canonical state
+    and the observations must be identical, which also ties the general layout's Chain-10 / ToyCtf behaviour to the traces."""
+    from marlon_amd._abi import RNG_PHILOX
+    _, sj = parity.load_trace(trace)
+    topo = parity.topology_for(trace)
+    E = 4096
+    spec = parity.spec_from_json(sj, n_envs=E, auto_reset=True, rng_kind=RNG_PHILOX, seed=99, max_episode_steps=120)
+    packed = _engine().BatchEngine(topo, spec)
+    monkeypatch.setenv("MCBS_NO_PACKED_SETS", "1")
+    general = _engine().BatchEngine(topo, spec)
+    monkeypatch.delenv("MCBS_NO_PACKED_SETS")
+    fields = list(parity.OBS_FIELDS)
+    for t in range(200):
+        a = packed.sample_actions(t % 4 != 0, seed=21, step=t)
+        if t % 20 == 19:
+            o1, o2 = packed.alloc_obs(fields), general.alloc_obs(fields)
+            r1, d1 = packed.step_observe(a, o1)
+            r2, d2 = general.step_observe(a, o2)
+            for f in fields:
+                assert packed.torch.equal(o1[f], o2[f]), f"step {t} obs {f}"
+        else:
+            r1, d1 = packed.step(a)
+            r2, d2 = general.step(a)
+        assert packed.torch.equal(r1, r2) and packed.torch.equal(d1, d2), f"step {t}"
+        for k in ("raw_reward", "truncated", "out_of_bound", "step_count", "network_availability"):
+            assert packed.torch.equal(packed.info[k], general.info[k]), f"step {t} info {k}"
+        if t % 50 == 49:
+            _compare_states(packed.get_state(), general.get_state(), f"{trace} step {t}")
+    packed.close()
+    general.close()
+
+
 def test_observations_match_oracle_batched():
     """Observation kernels vs the oracle's observation for 512 envs in mixed states (ToyCtf + defender)."""
     from marlon_amd._abi import RNG_PHILOX
