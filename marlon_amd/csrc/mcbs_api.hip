@@ -448,10 +448,19 @@ static int launch_obs(mcbs_batch* b, const mcbs_obs_buffers* o, hipStream_t st, 
     O.props = o->discovered_nodes_properties; O.priv = o->nodes_privilegelevel; O.mask_local = o->mask_local;
     O.mask_remote = o->mask_remote; O.mask_connect = o->mask_connect; O.mask_discrete = o->mask_discrete;
     O.Nmax = b->cfg.maximum_node_count; O.Cmax = b->cfg.maximum_total_credentials; O.K = b->cfg.maximum_discoverable_credentials_per_action;
+    // small action spaces: the per-env wavefront also writes mask_remote / mask_connect (mcbs_obs.hip)
+    const size_t rows = (size_t)O.Nmax * O.Nmax, RL = (size_t)b->C.P * O.Cmax;
+    const bool small = rows <= 256 && !getenv("MCBS_NO_FUSED_MASKS");
+    O.fuse_remote = small && o->mask_remote && (rows * b->C.R) % 4 == 0 && reinterpret_cast<uintptr_t>(o->mask_remote) % 4 == 0;
+    O.fuse_connect = small && o->mask_connect && RL % 16 == 0 && RL / 16 <= 64 && RL >= 16 &&
+                     reinterpret_cast<uintptr_t>(o->mask_connect) % 16 == 0;
     hipLaunchKernelGGL(obs_small_kernel, dim3((b->S.E + 3) / 4), dim3(256), 0, st, b->S, b->T, b->C, O, b->digest);
     int rc = launch_ok("obs_small");
     if (rc) return rc;
-    return launch_masks(b, o, st, env_mask, masks_only);
+    mcbs_obs_buffers rest = *o;                // what the fused wavefront has not written
+    if (O.fuse_remote) rest.mask_remote = nullptr;
+    if (O.fuse_connect) rest.mask_connect = nullptr;
+    return launch_masks(b, &rest, st, env_mask, masks_only);
 }
 
 template <int REGION>

@@ -155,6 +155,10 @@ struct ObsIO {
     uint32_t Nmax, Cmax, K;
     const uint8_t* env_mask; // optional [E]: only envs with a non-zero byte are written
     uint32_t masks_only;   // compute_action_mask: ignore the out-of-bound flag, write only mask fields
+    // small action spaces (<= 256 (source, target) pairs): the per-env wavefront of obs_small_kernel also streams the two big
+    // masks, so that one launch writes the whole observation and the digest never makes a round trip through memory
+    uint32_t fuse_remote;  // 1: mask_remote written by obs_small_kernel
+    uint32_t fuse_connect; // 1: mask_connect written by obs_small_kernel (row length P*C a multiple of 16, 16-byte aligned)
 };
 
 // ------------------------------ Philox4x32-10 (Random123) ------------------------------

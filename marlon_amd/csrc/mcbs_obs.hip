@@ -27,6 +27,7 @@ static_assert(sizeof(ObsDigest) == 64, "digest");
 
 __global__ __launch_bounds__(256) void obs_small_kernel(DevState S, Topo T, StepCfg C, ObsIO O, ObsDigest* digest) {
     __shared__ uint8_t ext_of_all[4][256];
+    __shared__ uint4 pat_all[4][64];           // fused connect mask: the 16-byte chunks of one "on" row, per wavefront
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t e = blockIdx.x * 4u + wave;
     if (e >= S.E) return;                     // whole wavefront leaves together
@@ -137,6 +138,61 @@ local_mask:
             int8_t v = 0;
             if (!blank && i < n_disc && ((own_ext[i >> 6] >> (i & 63u)) & 1ull)) v = (int8_t)((NS[dl[i]].local_mask >> l) & 1u);
             out[idx] = v;
+        }
+    }
+    if (!(O.fuse_remote | O.fuse_connect)) return;
+    // ---- fused big masks (small action spaces: Nm*Nm <= 256 rows).  Row q = (source s, target t) is "on" when s is an owned
+    // discovered node and t a discovered one; a ballot per 64 rows leaves the row bits in scalar registers ----
+    const uint32_t rows = Nm * Nm;
+    uint64_t on[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+        if (k * 64u < rows) {                 // wave-uniform
+            const uint32_t q = k * 64u + lane, s = q / Nm, t = q - s * Nm;
+            on[k] = __ballot(!blank && q < rows && ((own_ext[(s >> 6) & 3u] >> (s & 63u)) & 1ull) && t < n_disc);
+        }
+    }
+    auto row_on = [&](uint32_t q) -> bool {
+        const uint32_t k = q >> 6;
+        const uint64_t w = k == 0 ? on[0] : (k == 1 ? on[1] : (k == 2 ? on[2] : on[3]));
+        return (w >> (q & 63u)) & 1ull;
+    };
+    if (O.fuse_remote) {                      // remote[s][t][r] = on(s, t): 4 bytes per lane and iteration (MR is a multiple of 4)
+        const uint32_t R = C.R, MR = rows * R;
+        uint32_t* out = reinterpret_cast<uint32_t*>(O.mask_remote + (size_t)e * MR);
+        for (uint32_t i0 = lane * 4u; i0 < MR; i0 += 256u) {
+            uint32_t v = 0;
+#pragma unroll
+            for (uint32_t b = 0; b < 4u; ++b) v |= (uint32_t)row_on((i0 + b) / R) << (8u * b);
+            out[i0 >> 2] = v;
+        }
+    }
+    if (O.fuse_connect) {
+        // connect[s][t][p][c] = on(s, t) && c < n_creds.  An "on" row is RL = P*C bytes of the pattern "n_creds ones, C - n_creds
+        // zeros" repeated P times; RL is a multiple of 16 here, so the row is cpr (<= 64) fixed 16-byte chunks: lane j builds
+        // chunk j once per env (LDS), then the wavefront streams rows * cpr chunks as `on(q) ? pattern[j] : 0`, one coalesced
+        // kilobyte per store instruction, with (row, chunk-in-row) advanced incrementally instead of divided out per chunk.
+        const uint32_t Cc = O.Cmax, RL = C.P * Cc, cpr = RL >> 4;
+        uint4* pat = pat_all[wave];
+        if (lane < cpr) {
+            uint32_t c = (lane * 16u) % Cc, w[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (uint32_t i = 0; i < 16u; ++i) {
+                w[i >> 2] |= (uint32_t)(c < n_creds) << (8u * (i & 3u));
+                c = c + 1u == Cc ? 0u : c + 1u;
+            }
+            pat[lane] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        uint4* out = reinterpret_cast<uint4*>(O.mask_connect + (size_t)e * rows * RL);
+        const uint32_t total = rows * cpr, dq = 64u / cpr, dj = 64u - dq * cpr;
+        uint32_t q = lane / cpr, j = lane - q * cpr;
+        for (uint32_t c = lane; c < total; c += 64u) {
+            const uint4 p = pat[j];
+            out[c] = row_on(q) ? p : make_uint4(0, 0, 0, 0);
+            j += dj; q += dq;
+            if (j >= cpr) { j -= cpr; q += 1u; }
         }
     }
 }
