@@ -25,14 +25,31 @@ struct ObsDigest {          // 64 bytes per env
 };
 static_assert(sizeof(ObsDigest) == 64, "digest");
 
+// Per-wavefront staging area of obs_small_kernel: everything the observation of one env needs, by EXTERNAL index (position in
+// the discovery order) for nodes and by cache position for credentials.
+struct ObsStage {
+    uint64_t props[256];     // discovered properties of the node at external index i
+    uint32_t lmask[256];     // its local-vulnerability mask (static)
+    uint8_t  ext_of[256];    // node id -> external index
+    uint8_t  priv[256];      // privilege level of the node at external index i
+    uint8_t  cred_node[256]; // node id of cached credential r
+    uint8_t  cred_port[256]; // port index of cached credential r
+    uint4    pat[64];        // fused connect mask: the 16-byte chunks of one "on" row
+};
+
+// Structure: ALL loads first, then ALL stores.  On gfx9 loads and stores share the vmcnt counter and retire in order, so a
+// load issued after a store waits for that store's write acknowledgement; a first version that interleaved "load what this
+// field needs, store the field" per field spent most of a wavefront's ~25 us lifetime in such waits.  Now lane i fetches
+// everything about discovered node i and lane r everything about cached credential r in one burst (three dependent levels:
+// header; the two lists; rows / static tables), parks it in LDS by external index, and the rest of the kernel only computes
+// from LDS and streams stores.
 __global__ __launch_bounds__(256) void obs_small_kernel(DevState S, Topo T, StepCfg C, ObsIO O, ObsDigest* digest) {
-    __shared__ uint8_t ext_of_all[4][256];
-    __shared__ uint4 pat_all[4][64];           // fused connect mask: the 16-byte chunks of one "on" row, per wavefront
+    __shared__ ObsStage stage_all[4];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t e = blockIdx.x * 4u + wave;
     if (e >= S.E) return;                     // whole wavefront leaves together
     if (O.env_mask && !O.env_mask[e]) return; // wave-uniform: one wavefront per env
-    uint8_t* ext_of = ext_of_all[wave];
+    ObsStage& st = stage_all[wave];
     const uint4 h0 = S.h0[e];
     const uint32_t flags = h0.y, n_disc = h0.z & 0xFFFFu, n_creds = h0.z >> 16;
     if (!O.masks_only && (flags & F_SKIP)) return;   // split step, skip action: the env's previous observation stands
@@ -46,23 +63,33 @@ __global__ __launch_bounds__(256) void obs_small_kernel(DevState S, Topo T, Step
     const mcbs_triple* TR = reinterpret_cast<const mcbs_triple*>(T.base + C.off_triple);
     const uint32_t Nm = O.Nmax, NP = C.n_props, L = C.L;
 
+    // ---------------- loads ----------------
     uint64_t own_ext[4] = {0, 0, 0, 0};
 #pragma unroll
     for (uint32_t c = 0; c < 4; ++c) {
         const uint32_t i = c * 64u + lane;
-        bool own = false;
         if (c * 64u < n_disc) {               // wave-uniform
+            bool own = false;
             if (i < n_disc) {
                 const uint32_t n = dl[i];
-                ext_of[n] = (uint8_t)i;
                 own = S.has(M_INST, n, e);
+                st.ext_of[n] = (uint8_t)i;
+                st.props[i] = S.row_get(body, n).props_tags & ROW_PROPS_MASK;
+                st.lmask[i] = NS[n].local_mask;
+                st.priv[i] = (uint8_t)((uint32_t)S.has(M_PLO, n, e) | ((uint32_t)S.has(M_PHI, n, e) << 1));
             }
             own_ext[c] = __ballot(own);
+        }
+        if (c * 64u < n_creds && i < n_creds) {
+            const mcbs_triple t = TR[cl[i]];
+            st.cred_node[i] = (uint8_t)t.node;
+            st.cred_port[i] = (uint8_t)t.port;
         }
     }
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
 
+    // ---------------- stores only from here on ----------------
     if (lane == 0) {
         ObsDigest d;
         for (int c = 0; c < 4; ++c) d.own_ext[c] = blank ? 0ull : own_ext[c];
@@ -71,72 +98,65 @@ __global__ __launch_bounds__(256) void obs_small_kernel(DevState S, Topo T, Step
         digest[e] = d;
     }
 
-    if (O.masks_only) goto local_mask;
-    if (O.scalars && lane < 7) {
-        int32_t v = 0;
-        if (lane == 6) v = (int32_t)n_disc;
-        else if (!blank) {
-            if (lane == 0) v = (kind == MCBS_OUT_LEAKED_NODES || kind == MCBS_OUT_LEAKED_CREDENTIALS) ? (int32_t)new_nodes : 0;
-            else if (lane == 1) v = kind == MCBS_OUT_LATERAL_MOVE;
-            else if (lane == 2) v = kind == MCBS_OUT_CUSTOMER_DATA;
-            else if (lane == 3) v = kind == MCBS_OUT_PROBE_SUCCEEDED ? 2 : (kind == MCBS_OUT_PROBE_FAILED ? 1 : 0);
-            else if (lane == 4) v = kind == MCBS_OUT_PRIVILEGE_ESCALATION ? (int32_t)level : 0;
-            else v = (int32_t)n_creds;
-        }
-        O.scalars[(size_t)e * 7 + lane] = v;
-    }
-    if (O.leaked) {
-        int32_t* out = O.leaked + (size_t)e * O.K * 4;
-        const bool have = !blank && kind == MCBS_OUT_LEAKED_CREDENTIALS;
-        for (uint32_t idx = lane; idx < O.K * 4u; idx += 64u) {
-            const uint32_t r = idx >> 2, c = idx & 3u;
+    if (!O.masks_only) {
+        if (O.scalars && lane < 7) {
             int32_t v = 0;
-            if (have && r < new_creds) {
-                const uint32_t ci = n_creds - new_creds + r;
-                const mcbs_triple t = TR[cl[ci]];
-                v = c == 0 ? 1 : c == 1 ? (int32_t)ci : c == 2 ? (int32_t)ext_of[t.node] : (int32_t)t.port;
+            if (lane == 6) v = (int32_t)n_disc;
+            else if (!blank) {
+                if (lane == 0) v = (kind == MCBS_OUT_LEAKED_NODES || kind == MCBS_OUT_LEAKED_CREDENTIALS) ? (int32_t)new_nodes : 0;
+                else if (lane == 1) v = kind == MCBS_OUT_LATERAL_MOVE;
+                else if (lane == 2) v = kind == MCBS_OUT_CUSTOMER_DATA;
+                else if (lane == 3) v = kind == MCBS_OUT_PROBE_SUCCEEDED ? 2 : (kind == MCBS_OUT_PROBE_FAILED ? 1 : 0);
+                else if (lane == 4) v = kind == MCBS_OUT_PRIVILEGE_ESCALATION ? (int32_t)level : 0;
+                else v = (int32_t)n_creds;
             }
-            out[idx] = v;
+            O.scalars[(size_t)e * 7 + lane] = v;
         }
-    }
-    if (O.cache_matrix) {
-        int32_t* out = O.cache_matrix + (size_t)e * O.Cmax * 2;
-        for (uint32_t idx = lane; idx < O.Cmax * 2u; idx += 64u) {
-            const uint32_t r = idx >> 1;
-            int32_t v = 0;
-            if (!blank && r < n_creds) {
-                const mcbs_triple t = TR[cl[r]];
-                v = (idx & 1u) ? (int32_t)t.port : (int32_t)ext_of[t.node];
+        if (O.leaked) {
+            int32_t* out = O.leaked + (size_t)e * O.K * 4;
+            const bool have = !blank && kind == MCBS_OUT_LEAKED_CREDENTIALS;
+            for (uint32_t idx = lane; idx < O.K * 4u; idx += 64u) {
+                const uint32_t r = idx >> 2, c = idx & 3u;
+                int32_t v = 0;
+                if (have && r < new_creds) {
+                    const uint32_t ci = n_creds - new_creds + r;
+                    v = c == 0 ? 1 : c == 1 ? (int32_t)ci : c == 2 ? (int32_t)st.ext_of[st.cred_node[ci]] : (int32_t)st.cred_port[ci];
+                }
+                out[idx] = v;
             }
-            out[idx] = v;
         }
-    }
-    if (O.props) {
-        int32_t* out = O.props + (size_t)e * Nm * NP;
-        for (uint32_t i = 0; i < Nm; ++i) {   // one discovered node per iteration, lanes over properties
-            uint64_t pm = 0;
-            if (!blank && i < n_disc) pm = S.row_get(body, dl[i]).props_tags & ROW_PROPS_MASK;
-            for (uint32_t p = lane; p < NP; p += 64u) out[i * NP + p] = blank ? 2 : (int32_t)((pm >> p) & 1ull);
-        }
-    }
-    if (O.priv) {
-        int32_t* out = O.priv + (size_t)e * Nm;
-        for (uint32_t i = lane; i < Nm; i += 64u) {
-            int32_t v = 0;
-            if (!blank && i < n_disc) {
-                const uint32_t n = dl[i];
-                v = (int32_t)((uint32_t)S.has(M_PLO, n, e) | ((uint32_t)S.has(M_PHI, n, e) << 1));
+        if (O.cache_matrix) {
+            int32_t* out = O.cache_matrix + (size_t)e * O.Cmax * 2;
+            for (uint32_t idx = lane; idx < O.Cmax * 2u; idx += 64u) {
+                const uint32_t r = idx >> 1;
+                int32_t v = 0;
+                if (!blank && r < n_creds) v = (idx & 1u) ? (int32_t)st.cred_port[r] : (int32_t)st.ext_of[st.cred_node[r]];
+                out[idx] = v;
             }
-            out[i] = v;
+        }
+        if (O.props && NP) {
+            int32_t* out = O.props + (size_t)e * Nm * NP;
+            uint32_t i = lane / NP, p = lane - i * NP;             // (node, property) of flat index `lane`, then advanced by 64
+            const uint32_t di = 64u / NP, dp = 64u - di * NP;
+            for (uint32_t idx = lane; idx < Nm * NP; idx += 64u) {
+                int32_t v = blank ? 2 : 0;
+                if (!blank && i < n_disc) v = (int32_t)((st.props[i] >> p) & 1ull);
+                out[idx] = v;
+                p += dp; i += di;
+                if (p >= NP) { p -= NP; i += 1u; }
+            }
+        }
+        if (O.priv) {
+            int32_t* out = O.priv + (size_t)e * Nm;
+            for (uint32_t i = lane; i < Nm; i += 64u) out[i] = (!blank && i < n_disc) ? (int32_t)st.priv[i] : 0;
         }
     }
-local_mask:
     if (O.mask_local) {
         int8_t* out = O.mask_local + (size_t)e * Nm * L;
         for (uint32_t idx = lane; idx < Nm * L; idx += 64u) {
             const uint32_t i = idx / L, l = idx - i * L;
             int8_t v = 0;
-            if (!blank && i < n_disc && ((own_ext[i >> 6] >> (i & 63u)) & 1ull)) v = (int8_t)((NS[dl[i]].local_mask >> l) & 1u);
+            if (!blank && i < n_disc && ((own_ext[i >> 6] >> (i & 63u)) & 1ull)) v = (int8_t)((st.lmask[i] >> l) & 1u);
             out[idx] = v;
         }
     }
@@ -173,7 +193,6 @@ local_mask:
         // chunk j once per env (LDS), then the wavefront streams rows * cpr chunks as `on(q) ? pattern[j] : 0`, one coalesced
         // kilobyte per store instruction, with (row, chunk-in-row) advanced incrementally instead of divided out per chunk.
         const uint32_t Cc = O.Cmax, RL = C.P * Cc, cpr = RL >> 4;
-        uint4* pat = pat_all[wave];
         if (lane < cpr) {
             uint32_t c = (lane * 16u) % Cc, w[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -181,7 +200,7 @@ local_mask:
                 w[i >> 2] |= (uint32_t)(c < n_creds) << (8u * (i & 3u));
                 c = c + 1u == Cc ? 0u : c + 1u;
             }
-            pat[lane] = make_uint4(w[0], w[1], w[2], w[3]);
+            st.pat[lane] = make_uint4(w[0], w[1], w[2], w[3]);
         }
         __builtin_amdgcn_wave_barrier();
         __threadfence_block();
@@ -189,7 +208,7 @@ local_mask:
         const uint32_t total = rows * cpr, dq = 64u / cpr, dj = 64u - dq * cpr;
         uint32_t q = lane / cpr, j = lane - q * cpr;
         for (uint32_t c = lane; c < total; c += 64u) {
-            const uint4 p = pat[j];
+            const uint4 p = st.pat[j];
             out[c] = row_on(q) ? p : make_uint4(0, 0, 0, 0);
             j += dj; q += dq;
             if (j >= cpr) { j -= cpr; q += 1u; }
