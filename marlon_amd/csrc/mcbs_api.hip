@@ -454,12 +454,16 @@ static int launch_obs(mcbs_batch* b, const mcbs_obs_buffers* o, hipStream_t st, 
     O.fuse_remote = small && o->mask_remote && (rows * b->C.R) % 4 == 0 && reinterpret_cast<uintptr_t>(o->mask_remote) % 4 == 0;
     O.fuse_connect = small && o->mask_connect && RL % 16 == 0 && RL / 16 <= 64 && RL >= 16 &&
                      reinterpret_cast<uintptr_t>(o->mask_connect) % 16 == 0;
+    const size_t ML = (size_t)O.Nmax * b->C.L, MR = rows * b->C.R;
+    O.fuse_discrete = small && o->mask_discrete && RL % 4 == 0 && RL >= 4 && RL / 4 <= 256 && ML % 4 == 0 && MR % 4 == 0 && b->C.L > 0 &&
+                      b->C.R > 0 && reinterpret_cast<uintptr_t>(o->mask_discrete) % 4 == 0;
     hipLaunchKernelGGL(obs_small_kernel, dim3((b->S.E + 3) / 4), dim3(256), 0, st, b->S, b->T, b->C, O, b->digest);
     int rc = launch_ok("obs_small");
     if (rc) return rc;
     mcbs_obs_buffers rest = *o;                // what the fused wavefront has not written
     if (O.fuse_remote) rest.mask_remote = nullptr;
     if (O.fuse_connect) rest.mask_connect = nullptr;
+    if (O.fuse_discrete) rest.mask_discrete = nullptr;
     return launch_masks(b, &rest, st, env_mask, masks_only);
 }
 

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void obs_small_kernel(DevState S, Topo T, Step
             out[idx] = v;
         }
     }
-    if (!(O.fuse_remote | O.fuse_connect)) return;
+    if (!(O.fuse_remote | O.fuse_connect | O.fuse_discrete)) return;
     // ---- fused big masks (small action spaces: Nm*Nm <= 256 rows).  Row q = (source s, target t) is "on" when s is an owned
     // discovered node and t a discovered one; a ballot per 64 rows leaves the row bits in scalar registers ----
     const uint32_t rows = Nm * Nm;
@@ -212,6 +212,52 @@ __global__ __launch_bounds__(256) void obs_small_kernel(DevState S, Topo T, Step
             out[c] = row_on(q) ? p : make_uint4(0, 0, 0, 0);
             j += dj; q += dq;
             if (j >= cpr) { j -= cpr; q += 1u; }
+        }
+    }
+    if (O.fuse_discrete) {
+        // MaskedDiscreteAttackerWrapper.action_masks (action_masking.py:96-110): connect | local | remote, one flat int8 vector per
+        // env.  Its length is not a multiple of 16 in general (Chain-10: 14 172), so env bases are only 4-byte aligned and the
+        // three regions are streamed as dwords: the connect rows from a dword pattern row in LDS, like above.
+        const uint32_t Cc = O.Cmax, RL = C.P * Cc, dpr = RL >> 2, R = C.R;
+        const uint32_t M = rows * RL, ML = Nm * L, MR = rows * R;
+        uint32_t* pat = reinterpret_cast<uint32_t*>(st.pat);
+        __builtin_amdgcn_wave_barrier();               // (the 16-byte pattern above may still be in use by other lanes)
+        for (uint32_t jj = lane; jj < dpr; jj += 64u) {
+            uint32_t c = (jj * 4u) % Cc, w = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < 4u; ++i) {
+                w |= (uint32_t)(c < n_creds) << (8u * i);
+                c = c + 1u == Cc ? 0u : c + 1u;
+            }
+            pat[jj] = w;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        uint32_t* out = reinterpret_cast<uint32_t*>(O.mask_discrete + (size_t)e * (M + ML + MR));
+        const uint32_t total = rows * dpr, dq = 64u / dpr, dj = 64u - dq * dpr;
+        uint32_t q = lane / dpr, j = lane - q * dpr;
+        for (uint32_t c = lane; c < total; c += 64u) {
+            out[c] = row_on(q) ? pat[j] : 0u;
+            j += dj; q += dq;
+            if (j >= dpr) { j -= dpr; q += 1u; }
+        }
+        out += M >> 2;
+        for (uint32_t i0 = lane * 4u; i0 < ML; i0 += 256u) {      // local[i][l], same rule as mask_local
+            uint32_t v = 0;
+#pragma unroll
+            for (uint32_t b = 0; b < 4u; ++b) {
+                const uint32_t idx = i0 + b, i = idx / L, l = idx - i * L;
+                const bool bit = !blank && i < n_disc && ((own_ext[(i >> 6) & 3u] >> (i & 63u)) & 1ull) && ((st.lmask[i & 255u] >> l) & 1u);
+                v |= (uint32_t)bit << (8u * b);
+            }
+            out[i0 >> 2] = v;
+        }
+        out += ML >> 2;
+        for (uint32_t i0 = lane * 4u; i0 < MR; i0 += 256u) {
+            uint32_t v = 0;
+#pragma unroll
+            for (uint32_t b = 0; b < 4u; ++b) v |= (uint32_t)row_on((i0 + b) / R) << (8u * b);
+            out[i0 >> 2] = v;
         }
     }
 }

@@ -148,12 +148,15 @@ def test_general_layout_equals_packed_layout(trace, monkeypatch):
     general.close()
 
 
-def test_observations_match_oracle_batched():
-    """Observation kernels vs the oracle's observation for 512 envs in mixed states (ToyCtf + defender)."""
+@pytest.mark.parametrize("trace", ["toyctf_defender_s11", "chain10_mix_s3", "chain4_defender_s21", "random24_defender_s51"])
+def test_observations_match_oracle_batched(trace):
+    """Observation kernels vs the oracle's observation for 512 envs in mixed states.  ToyCtf (connect rows of 70 bytes) takes
+    the general mask kernels, Chain-10 / Chain-4 (96 / 48-byte rows) the masks fused into the per-env wavefront incl.
+    mask_discrete, the 24-node topology has more (source, target) pairs than the fused path takes."""
     from marlon_amd._abi import RNG_PHILOX
     from oracle.oracle import Oracle
-    _, sj = parity.load_trace("toyctf_defender_s11")
-    topo = parity.topology_for("toyctf")
+    _, sj = parity.load_trace(trace)
+    topo = parity.topology_for(trace)
     E = 512
     spec = parity.spec_from_json(sj, n_envs=E, auto_reset=True, rng_kind=RNG_PHILOX, seed=5)
     eng = _engine().BatchEngine(topo, spec)
