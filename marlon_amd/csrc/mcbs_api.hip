@@ -401,7 +401,12 @@ template <int PHASE, int WT, int DEF>
 static void launch_step_v(mcbs_batch* b, const StepIO& io, hipStream_t st) {
     const uint32_t E = b->S.E, lds = b->C.hot_bytes;
     if (lds <= 60000u && !getenv("MCBS_NO_LDS_TOPO")) {
-        const uint32_t block = lds <= 8192u ? 64u : 256u;
+        // workgroup size: as large as still leaves one workgroup per CU (256) — every workgroup stages its own copy of the hot
+        // image, so at 65 536 envs 64-thread workgroups re-read it 4x as often as 256-thread ones (5.79 vs 5.48 us/step), while
+        // 512 threads would leave half of the CUs idle (6.29 us)
+        uint32_t block = lds <= 8192u ? 64u : 256u;
+        while (block < 256u && E / (block * 2u) >= 256u) block *= 2u;
+        if (const char* ov = getenv("MCBS_STEP_BLOCK")) block = (uint32_t)atoi(ov);   // experiments only (64, 128 or 256)
         hipLaunchKernelGGL((step_kernel<PHASE, WT, true, DEF>), dim3((E + block - 1) / block), dim3(block), lds, st, b->S, b->T, b->C_dev, io);
     } else {
         hipLaunchKernelGGL((step_kernel<PHASE, WT, false, DEF>), dim3((E + 127) / 128), dim3(128), 0, st, b->S, b->T, b->C_dev, io);

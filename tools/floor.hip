@@ -59,6 +59,28 @@ __global__ __launch_bounds__(256) void traffic_cols_kernel(uint32_t* __restrict_
     out[e] = make_uint2(r0.x, r1.y);
 }
 
+// packed-batch shapes: header 16 + 16 + sets 16 (columns) + action 20, and the 96-byte body either as an array of structures
+// (7 x 16-byte loads per lane at stride 96: what the step kernel does) or as seven env-fastest 16-byte columns
+template <bool SOA>
+__global__ __launch_bounds__(64) void packed_kernel(uint4* __restrict__ h, uint4* __restrict__ body, const int* __restrict__ act,
+                                                    uint2* __restrict__ out, int E) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    uint4 h0 = h[e], h1 = h[(size_t)E + e], pk = h[(size_t)2 * E + e];
+    uint4 b[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) b[k] = SOA ? body[(size_t)k * E + e] : body[(size_t)e * 6 + k];
+    int a0 = act[e * 5 + 1];
+    uint32_t acc = h0.x + h1.y + pk.z + a0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) acc += b[k].x ^ b[k].w;
+    h0.x = acc; h1.y = acc; pk.z = acc;
+    h[e] = h0; h[(size_t)E + e] = h1; h[(size_t)2 * E + e] = pk;
+    uint32_t* rows = reinterpret_cast<uint32_t*>(SOA ? body + (size_t)(3 + ((a0 >> 2) % 3)) * E + e : body + (size_t)e * 6 + 3 + ((a0 >> 2) % 3));
+    rows[a0 & 3] = acc;
+    out[e] = make_uint2(acc, acc);
+}
+
 template <class F> static float replay(hipStream_t st, int K, F launch) {
     hipGraph_t g; hipGraphExec_t ge;
     CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
@@ -90,6 +112,12 @@ int main(int argc, char** argv) {
     dim3 grid64((E + 63) / 64), block64(64);
     float t2 = replay(st, K, [&] { hipLaunchKernelGGL(traffic_kernel, grid64, block64, 0, st, hdr, rows, act, out, E); });
     float t3 = replay(st, K, [&] { hipLaunchKernelGGL(traffic_cols_kernel, grid, block, 0, st, hdr, (uint2*)rows, act, out, E); });
+    uint4* hp; uint4* bp;
+    CK(hipMalloc(&hp, (size_t)E * 48)); CK(hipMalloc(&bp, (size_t)E * 96));
+    CK(hipMemset(hp, 0, (size_t)E * 48)); CK(hipMemset(bp, 0, (size_t)E * 96));
+    float t4 = replay(st, K, [&] { hipLaunchKernelGGL((packed_kernel<false>), grid64, block64, 0, st, hp, bp, act, out, E); });
+    float t5 = replay(st, K, [&] { hipLaunchKernelGGL((packed_kernel<true>), grid64, block64, 0, st, hp, bp, act, out, E); });
+    printf("{\"packed_aos_us\": %.3f, \"packed_soa_us\": %.3f}\n", t4, t5);
     printf("{\"envs\": %d, \"empty_us\": %.3f, \"traffic_only_us\": %.3f, \"traffic_only_wg64_us\": %.3f, \"bytes_per_env\": %d, "
            "\"row_columns_us\": %.3f}\n", E, t0, t1, t2, 20 + 64 + 64 + 8, t3);
     return 0;
