@@ -457,11 +457,15 @@ static int launch_obs(mcbs_batch* b, const mcbs_obs_buffers* o, hipStream_t st, 
     const size_t rows = (size_t)O.Nmax * O.Nmax, RL = (size_t)b->C.P * O.Cmax;
     const bool small = rows <= 256 && !getenv("MCBS_NO_FUSED_MASKS");
     O.fuse_remote = small && o->mask_remote && (rows * b->C.R) % 4 == 0 && reinterpret_cast<uintptr_t>(o->mask_remote) % 4 == 0;
-    O.fuse_connect = small && o->mask_connect && RL % 16 == 0 && RL / 16 <= 64 && RL >= 16 &&
-                     reinterpret_cast<uintptr_t>(o->mask_connect) % 16 == 0;
-    const size_t ML = (size_t)O.Nmax * b->C.L, MR = rows * b->C.R;
-    O.fuse_discrete = small && o->mask_discrete && RL % 4 == 0 && RL >= 4 && RL / 4 <= 256 && ML % 4 == 0 && MR % 4 == 0 && b->C.L > 0 &&
-                      b->C.R > 0 && reinterpret_cast<uintptr_t>(o->mask_discrete) % 4 == 0;
+    const size_t ML = (size_t)O.Nmax * b->C.L, MR = rows * b->C.R, M = rows * RL;
+    const bool dwords_ok = small && RL >= 4 && RL + 4 <= 1040 && M % 4 == 0;     // the row pattern fits its kilobyte of LDS
+    O.fuse_connect = 0;
+    if (small && o->mask_connect) {
+        if (RL % 16 == 0 && RL / 16 <= 64 && reinterpret_cast<uintptr_t>(o->mask_connect) % 16 == 0) O.fuse_connect = 1;   // 16-byte chunks
+        else if (dwords_ok && reinterpret_cast<uintptr_t>(o->mask_connect) % 4 == 0) O.fuse_connect = 2;                    // dwords, any RL
+    }
+    O.fuse_discrete = dwords_ok && o->mask_discrete && ML % 4 == 0 && MR % 4 == 0 && b->C.L > 0 && b->C.R > 0 &&
+                      reinterpret_cast<uintptr_t>(o->mask_discrete) % 4 == 0;
     hipLaunchKernelGGL(obs_small_kernel, dim3((b->S.E + 3) / 4), dim3(256), 0, st, b->S, b->T, b->C, O, b->digest);
     int rc = launch_ok("obs_small");
     if (rc) return rc;

@@ -34,7 +34,8 @@ struct ObsStage {
     uint8_t  priv[256];      // privilege level of the node at external index i
     uint8_t  cred_node[256]; // node id of cached credential r
     uint8_t  cred_port[256]; // port index of cached credential r
-    uint4    pat[64];        // fused connect mask: the 16-byte chunks of one "on" row
+    uint4    pat[65];        // fused connect mask: the bytes of one "on" row (+ the first 4 again), <= 1 040
+    uint8_t  onb[260];       // fused masks: row q = (source, target) is on
 };
 
 // Structure: ALL loads first, then ALL stores.  On gfx9 loads and stores share the vmcnt counter and retire in order, so a
@@ -169,9 +170,12 @@ __global__ __launch_bounds__(256) void obs_small_kernel(DevState S, Topo T, Step
     for (uint32_t k = 0; k < 4; ++k) {
         if (k * 64u < rows) {                 // wave-uniform
             const uint32_t q = k * 64u + lane, s = q / Nm, t = q - s * Nm;
-            on[k] = __ballot(!blank && q < rows && ((own_ext[(s >> 6) & 3u] >> (s & 63u)) & 1ull) && t < n_disc);
+            const bool v = !blank && q < rows && ((own_ext[(s >> 6) & 3u] >> (s & 63u)) & 1ull) && t < n_disc;
+            on[k] = __ballot(v);
+            st.onb[q] = v ? 1 : 0;
         }
     }
+    if (lane < 4u) st.onb[256u + lane] = 0;   // (row `rows` is read, never used, when the last dword ends exactly at the end)
     auto row_on = [&](uint32_t q) -> bool {
         const uint32_t k = q >> 6;
         const uint64_t w = k == 0 ? on[0] : (k == 1 ? on[1] : (k == 2 ? on[2] : on[3]));
@@ -187,7 +191,42 @@ __global__ __launch_bounds__(256) void obs_small_kernel(DevState S, Topo T, Step
             out[i0 >> 2] = v;
         }
     }
-    if (O.fuse_connect) {
+    // General form of the connect region, any row length RL (ToyCtf: 70 bytes), as dwords: the bytes of one "on" row sit in LDS
+    // followed by its first four bytes again, so the dword at row offset r is two aligned LDS words shifted by r & 3; the bytes
+    // that spill into the next row take that row's on/off.  (row, offset) advance incrementally by 256 bytes per iteration.
+    auto stream_connect_dwords = [&](uint32_t* out) {
+        const uint32_t Cc = O.Cmax, RL = C.P * Cc, nw = (RL + 4u + 3u) >> 2;
+        uint32_t* pat = reinterpret_cast<uint32_t*>(st.pat);
+        __builtin_amdgcn_wave_barrier();               // (an earlier pattern may still be in use by other lanes)
+        for (uint32_t wd = lane; wd < nw; wd += 64u) {
+            uint32_t r = wd * 4u, w = 0;
+            if (r >= RL) r -= RL;
+            uint32_t c = r % Cc;
+#pragma unroll
+            for (uint32_t i = 0; i < 4u; ++i) {
+                w |= (uint32_t)(c < n_creds) << (8u * i);
+                r += 1u; c += 1u;
+                if (c == Cc) c = 0u;
+                if (r == RL) { r = 0u; c = 0u; }
+            }
+            pat[wd] = w;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        const uint32_t total = (rows * RL) >> 2, dq = 256u / RL, dr = 256u - dq * RL;
+        uint32_t b0 = lane * 4u, q = b0 / RL, r = b0 - q * RL;
+        for (uint32_t k = lane; k < total; k += 64u) {
+            const uint32_t lo = pat[r >> 2], hi = pat[(r >> 2) + 1u];
+            const uint32_t w = __builtin_amdgcn_alignbyte(hi, lo, r & 3u);
+            const uint32_t nb = RL - r;                                   // bytes of this dword inside row q (>= 4: all)
+            const uint32_t mq = nb >= 4u ? 0xFFFFFFFFu : ((1u << (8u * nb)) - 1u);
+            out[k] = w & ((st.onb[q] ? mq : 0u) | (st.onb[q + 1u] ? ~mq : 0u));
+            r += dr; q += dq;
+            if (r >= RL) { r -= RL; q += 1u; }
+        }
+    };
+    if (O.fuse_connect == 2u) stream_connect_dwords(reinterpret_cast<uint32_t*>(O.mask_connect + (size_t)e * rows * C.P * O.Cmax));
+    if (O.fuse_connect == 1u) {
         // connect[s][t][p][c] = on(s, t) && c < n_creds.  An "on" row is RL = P*C bytes of the pattern "n_creds ones, C - n_creds
         // zeros" repeated P times; RL is a multiple of 16 here, so the row is cpr (<= 64) fixed 16-byte chunks: lane j builds
         // chunk j once per env (LDS), then the wavefront streams rows * cpr chunks as `on(q) ? pattern[j] : 0`, one coalesced
@@ -217,30 +256,11 @@ __global__ __launch_bounds__(256) void obs_small_kernel(DevState S, Topo T, Step
     if (O.fuse_discrete) {
         // MaskedDiscreteAttackerWrapper.action_masks (action_masking.py:96-110): connect | local | remote, one flat int8 vector per
         // env.  Its length is not a multiple of 16 in general (Chain-10: 14 172), so env bases are only 4-byte aligned and the
-        // three regions are streamed as dwords: the connect rows from a dword pattern row in LDS, like above.
-        const uint32_t Cc = O.Cmax, RL = C.P * Cc, dpr = RL >> 2, R = C.R;
+        // three regions are streamed as dwords.
+        const uint32_t RL = C.P * O.Cmax, R = C.R;
         const uint32_t M = rows * RL, ML = Nm * L, MR = rows * R;
-        uint32_t* pat = reinterpret_cast<uint32_t*>(st.pat);
-        __builtin_amdgcn_wave_barrier();               // (the 16-byte pattern above may still be in use by other lanes)
-        for (uint32_t jj = lane; jj < dpr; jj += 64u) {
-            uint32_t c = (jj * 4u) % Cc, w = 0;
-#pragma unroll
-            for (uint32_t i = 0; i < 4u; ++i) {
-                w |= (uint32_t)(c < n_creds) << (8u * i);
-                c = c + 1u == Cc ? 0u : c + 1u;
-            }
-            pat[jj] = w;
-        }
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
         uint32_t* out = reinterpret_cast<uint32_t*>(O.mask_discrete + (size_t)e * (M + ML + MR));
-        const uint32_t total = rows * dpr, dq = 64u / dpr, dj = 64u - dq * dpr;
-        uint32_t q = lane / dpr, j = lane - q * dpr;
-        for (uint32_t c = lane; c < total; c += 64u) {
-            out[c] = row_on(q) ? pat[j] : 0u;
-            j += dj; q += dq;
-            if (j >= dpr) { j -= dpr; q += 1u; }
-        }
+        stream_connect_dwords(out);
         out += M >> 2;
         for (uint32_t i0 = lane * 4u; i0 < ML; i0 += 256u) {      // local[i][l], same rule as mask_local
             uint32_t v = 0;
