@@ -43,7 +43,7 @@ extern "C" {
 #define MCBS_MAX_SLOTS         32   /* vulnerabilities applicable to one node (library + own) */
 #define MCBS_MAX_LOCAL_VULNS   32   /* local-vulnerability mask per node is u32 */
 #define MCBS_MAX_CRED_STRINGS 256    /* every set is held in <= 4 x u64 registers per env */
-#define MCBS_MAX_TRIPLES      256   /* distinct (node, port, credential) triples */
+#define MCBS_MAX_TRIPLES      1024  /* distinct (node, port, credential) triples; more than 256 are kept as a wide set in memory */
 
 /* ================================================================================
  * Topology blob ("MCBT", little endian, every section 16-byte aligned).

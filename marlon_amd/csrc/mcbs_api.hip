@@ -238,9 +238,9 @@ extern "C" int mcbs_batch_create(const mcbs_topology* topo, const mcbs_batch_cfg
     if (cfg->defender_kind > MCBS_DEFENDER_EXTERNAL) return fail(MCBS_EINVAL, "unknown defender kind");
     if (cfg->defender_kind == MCBS_DEFENDER_SCAN_AND_REIMAGE && cfg->scan_frequency == 0) return fail(MCBS_EINVAL, "scan_frequency must be positive");
     if (cfg->rng_kind > MCBS_RNG_TAPE) return fail(MCBS_EINVAL, "unknown rng kind");
-    if (h->n_cred_strings > 256u || h->n_triples > 256u)
-        return fail(MCBS_ELIMIT, "this build keeps every set in <= 4 x 64-bit registers per env: at most 256 credential strings / triples "
-                    "(topology has %u / %u)", h->n_cred_strings, h->n_triples);
+    if (h->n_cred_strings > MCBS_MAX_CRED_STRINGS || h->n_triples > MCBS_MAX_TRIPLES)
+        return fail(MCBS_ELIMIT, "at most %d credential strings / %d triples (topology has %u / %u)", MCBS_MAX_CRED_STRINGS, MCBS_MAX_TRIPLES,
+                    h->n_cred_strings, h->n_triples);
 
     mcbs_batch* b = new (std::nothrow) mcbs_batch();
     if (!b) return fail(MCBS_ENOMEM, "out of memory");
@@ -270,9 +270,11 @@ extern "C" int mcbs_batch_create(const mcbs_topology* topo, const mcbs_batch_cfg
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     const size_t o_h0 = take(16ull * E), o_h1 = take(16ull * E), o_ep = take(4ull * E), o_pend = take(8ull * E);
     uint32_t wt = S.NW > S.SW ? S.NW : S.SW;
-    if (S.TW > wt) wt = S.TW;
+    S.wide = S.TW > 4u ? 1u : 0u;             // the cached-triple set does not fit 4 words: own column array (DevState::cach)
+    if (!S.wide && S.TW > wt) wt = S.TW;
     S.WT = wt <= 1 ? 1 : (wt == 2 ? 2 : 4);
     const size_t o_masks = take(S.packed ? 16ull * E : 8ull * M_COUNT * S.WT * E);
+    const size_t o_cach = S.wide ? take(8ull * S.TW * E) : 0;
     const bool has_def = cfg->defender_kind != MCBS_DEFENDER_NONE;   // in-env or external: both re-image nodes
     const size_t o_ring = has_def ? take(8ull * 16 * S.WT * E) : 0;
     const size_t o_init = take(S.body_stride);
@@ -287,6 +289,7 @@ extern "C" int mcbs_batch_create(const mcbs_topology* topo, const mcbs_batch_cfg
     S.h0 = reinterpret_cast<uint4*>(a + o_h0); S.h1 = reinterpret_cast<double2*>(a + o_h1);
     S.episode = reinterpret_cast<uint32_t*>(a + o_ep); S.pending = reinterpret_cast<double*>(a + o_pend);
     S.masks = reinterpret_cast<uint64_t*>(a + o_masks);
+    S.cach = S.wide ? reinterpret_cast<uint64_t*>(a + o_cach) : nullptr;
     S.ring = has_def ? reinterpret_cast<uint64_t*>(a + o_ring) : nullptr;
     S.body = a + o_body; S.init_body = a + o_init;
     b->digest = reinterpret_cast<ObsDigest*>(a + o_digest);
@@ -373,7 +376,15 @@ static StepIO make_io(mcbs_batch* b, const int32_t* actions, float* reward, uint
         io.oob = info->out_of_bound; io.raw_reward = info->raw_reward;
     }
     io.tape = b->tape; io.tape_dps = b->tape_dps;
+#ifdef MCBS_DIAG
     io.stamps = b->stamps;
+#endif
+    // Kernel-argument budget: DevState + Topo + config pointer + StepIO are followed by the hidden launch arguments; the block
+    // size the kernel reads first sits 12 bytes in.  When that crossed byte 256 the step took 5.73 instead of 5.47 us — a step
+    // function (64 or 128 bytes more cost the same), as if only the first 256 bytes of the arguments are prefetched for the waves.
+#ifndef MCBS_DIAG
+    static_assert(sizeof(DevState) + sizeof(Topo) + sizeof(void*) + sizeof(StepIO) + 16 <= 256, "step kernel arguments spill into a fifth cache line");
+#endif
     return io;
 }
 
@@ -407,9 +418,11 @@ static void launch_step_v(mcbs_batch* b, const StepIO& io, hipStream_t st) {
         uint32_t block = lds <= 8192u ? 64u : 256u;
         while (block < 256u && E / (block * 2u) >= 256u) block *= 2u;
         if (const char* ov = getenv("MCBS_STEP_BLOCK")) block = (uint32_t)atoi(ov);   // experiments only (64, 128 or 256)
-        hipLaunchKernelGGL((step_kernel<PHASE, WT, true, DEF>), dim3((E + block - 1) / block), dim3(block), lds, st, b->S, b->T, b->C_dev, io);
+        hipLaunchKernelGGL((step_kernel<PHASE, WT, true, DEF>), dim3((E + block - 1) / block), dim3(block), lds + (b->S.wide ? block * b->S.TW * 8u : 0u), st,
+                           b->S, b->T, b->C_dev, io);
     } else {
-        hipLaunchKernelGGL((step_kernel<PHASE, WT, false, DEF>), dim3((E + 127) / 128), dim3(128), 0, st, b->S, b->T, b->C_dev, io);
+        hipLaunchKernelGGL((step_kernel<PHASE, WT, false, DEF>), dim3((E + 127) / 128), dim3(128), b->S.wide ? 128u * b->S.TW * 8u : 0u, st,
+                           b->S, b->T, b->C_dev, io);
     }
 }
 
@@ -466,7 +479,8 @@ static int launch_obs(mcbs_batch* b, const mcbs_obs_buffers* o, hipStream_t st, 
     }
     O.fuse_discrete = dwords_ok && o->mask_discrete && ML % 4 == 0 && MR % 4 == 0 && b->C.L > 0 && b->C.R > 0 &&
                       reinterpret_cast<uintptr_t>(o->mask_discrete) % 4 == 0;
-    hipLaunchKernelGGL(obs_small_kernel, dim3((b->S.E + 3) / 4), dim3(256), 0, st, b->S, b->T, b->C, O, b->digest);
+    hipLaunchKernelGGL(obs_small_kernel, dim3((b->S.E + 3) / 4), dim3(256), 4u * obs_stage_bytes(b->S.N, b->topo->H()->n_triples), st,
+                       b->S, b->T, b->C, O, b->digest);
     int rc = launch_ok("obs_small");
     if (rc) return rc;
     mcbs_obs_buffers rest = *o;                // what the fused wavefront has not written
@@ -631,6 +645,7 @@ extern "C" int mcbs_get_state(mcbs_batch* b, void* host_buf, size_t nbytes) {
     const uint32_t* ep = reinterpret_cast<const uint32_t*>(at(S.episode));
     const void* mk = at(S.masks);
     auto has = [&](int k, uint32_t n, uint32_t e) { return ((S.set_word(mk, k, n >> 6, e) >> (n & 63u)) & 1ull) != 0; };
+    (void)has;
     const uint64_t* ring = S.ring ? reinterpret_cast<const uint64_t*>(at(S.ring)) : nullptr;
     const uint8_t* body = at(S.body);
     memset(host_buf, 0, rb * S.E);
@@ -685,7 +700,11 @@ extern "C" int mcbs_set_state(mcbs_batch* b, const void* host_buf, size_t nbytes
     double2* h1 = reinterpret_cast<double2*>(at(S.h1));
     uint32_t* ep = reinterpret_cast<uint32_t*>(at(S.episode));
     void* mk = at(S.masks);
-    auto add = [&](int k, uint32_t n, uint32_t e) { S.put_word(mk, k, n >> 6, e, S.set_word(mk, k, n >> 6, e) | (1ull << (n & 63u))); };
+    uint64_t* cach_h = S.wide ? reinterpret_cast<uint64_t*>(at(S.cach)) : nullptr;
+    auto add = [&](int k, uint32_t n, uint32_t e) {
+        if (cach_h && k == M_CACH) cach_h[(size_t)(n >> 6) * S.E + e] |= 1ull << (n & 63u);
+        else S.put_word(mk, k, n >> 6, e, S.set_word(mk, k, n >> 6, e) | (1ull << (n & 63u)));
+    };
     uint64_t* ring = S.ring ? reinterpret_cast<uint64_t*>(at(S.ring)) : nullptr;
     uint8_t* body = at(S.body);
     const mcbs_triple* tr = reinterpret_cast<const mcbs_triple*>(b->topo->host.data() + th->off_triple);
@@ -698,6 +717,7 @@ extern "C" int mcbs_set_state(mcbs_batch* b, const void* host_buf, size_t nbytes
         if (sh->n_discovered > S.N || sh->n_creds > th->n_triples) return fail(MCBS_EINVAL, "env %u: list lengths out of range", e);
         for (uint32_t w = 0; w < S.WT; ++w) {
             for (int k = 0; k < M_COUNT; ++k) S.put_word(mk, k, w, e, 0ull);
+            if (cach_h && w == 0) for (uint32_t cw = 0; cw < S.TW; ++cw) cach_h[(size_t)cw * S.E + e] = 0ull;
             if (ring) for (uint32_t s = 0; s < 16u; ++s) ring[((size_t)s * S.WT + w) * S.E + e] = 0;
         }
         uint8_t* eb = body + (size_t)e * S.body_stride;

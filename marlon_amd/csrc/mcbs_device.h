@@ -77,13 +77,22 @@ struct DevState {
         if (packed) static_cast<uint16_t*>(base)[(size_t)e * M_COUNT + (uint32_t)k] = (uint16_t)v;
         else static_cast<uint64_t*>(base)[((size_t)k * WT + w) * E + e] = v;
     }
-    __device__ __forceinline__ uint64_t get(int k, uint32_t w, uint32_t e) const { return set_word(masks, k, w, e); }
-    __device__ __forceinline__ void put(int k, uint32_t w, uint32_t e, uint64_t v) const { put_word(masks, k, w, e, v); }
+    __device__ __forceinline__ uint64_t get(int k, uint32_t w, uint32_t e) const {
+        return (wide && k == M_CACH) ? cach[(size_t)w * E + e] : set_word(masks, k, w, e);
+    }
+    __device__ __forceinline__ void put(int k, uint32_t w, uint32_t e, uint64_t v) const {
+        if (wide && k == M_CACH) cach[(size_t)w * E + e] = v;
+        else put_word(masks, k, w, e, v);
+    }
     __device__ __forceinline__ bool has(int k, uint32_t n, uint32_t e) const { return (get(k, n >> 6, e) >> (n & 63u)) & 1ull; }
     uint64_t* ring;     // [16][NW][E] nodes being re-imaged, by the defender tick (mod 16) that releases them; null without defender
     uint8_t*  body;     // [E][body_stride]
     const uint8_t* init_body; // [body_stride] image of a freshly reset env
     uint32_t E, N, NW, SW, TW, WT;  // WT = words per set = max(NW, SW, TW) rounded to 1, 2 or 4
+    uint64_t* cach;     // [TW][E]: the cached-triple set when it needs more than 4 words (`wide`: ActiveDirectory networks cache up to
+                        // ~800 (node, port, credential) triples); it then lives here instead of in masks / registers, and the step
+                        // kernel stages a lane's words in LDS only while a credential-leak payload is processed
+    uint32_t wide;
     uint32_t packed;    // 1: the sets of an env are 16-bit fields of one uint4 (see masks) and its node rows are 4 bytes each:
     uint32_t tiny_p, tiny_v;   // properties (tiny_p bits) | tags (4) | attacked-ever (tiny_v bits) | attacked-since (tiny_v bits) <= 32 bits,
                         // so that the whole body (discovery order 16 B, credential cache 32 B, <= 16 rows 64 B) is fetched with the header
@@ -146,7 +155,10 @@ struct StepIO {
     float* raw_reward;
     const double* tape;
     uint32_t tape_dps;
-    unsigned long long* stamps;  // diagnostic builds only (-DMCBS_DIAG): [waves][8] s_memtime stamps
+#ifdef MCBS_DIAG
+    unsigned long long* stamps;  // diagnostic builds only: [waves][8] s_memtime stamps.  Kept out of the product build: the step
+                                 // kernel's arguments must end below byte 256 (see mcbs_api.hip make_io)
+#endif
 };
 
 struct ObsIO {
@@ -203,7 +215,8 @@ __device__ __forceinline__ void reset_header(const DevState& S, const Topo& T, u
         S.put(M_RUN, w, e, rem >= 64u ? ~0ull : ((1ull << rem) - 1ull));
         if (S.ring) for (uint32_t s = 0; s < 16u; ++s) S.ring[((size_t)s * S.WT + w) * S.E + e] = 0;
     }
-    for (uint32_t w = 0; w < S.WT; ++w) { S.put(M_GATH, w, e, 0ull); S.put(M_CACH, w, e, 0ull); }
+    for (uint32_t w = 0; w < S.WT; ++w) { S.put(M_GATH, w, e, 0ull); S.put_word(S.masks, M_CACH, w, e, 0ull); }
+    if (S.wide) for (uint32_t w = 0; w < S.TW; ++w) S.cach[(size_t)w * S.E + e] = 0ull;
     for (uint32_t w = S.NW; w < S.WT; ++w)
         for (int k = 0; k < M_GATH; ++k) S.put(k, w, e, 0ull);
     S.h0[e] = make_uint4(0u, 0u, n_init, n_init);

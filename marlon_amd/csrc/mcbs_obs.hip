@@ -27,16 +27,33 @@ static_assert(sizeof(ObsDigest) == 64, "digest");
 
 // Per-wavefront staging area of obs_small_kernel: everything the observation of one env needs, by EXTERNAL index (position in
 // the discovery order) for nodes and by cache position for credentials.
-struct ObsStage {
-    uint64_t props[256];     // discovered properties of the node at external index i
-    uint32_t lmask[256];     // its local-vulnerability mask (static)
-    uint8_t  ext_of[256];    // node id -> external index
-    uint8_t  priv[256];      // privilege level of the node at external index i
-    uint8_t  cred_node[256]; // node id of cached credential r
-    uint8_t  cred_port[256]; // port index of cached credential r
-    uint4    pat[65];        // fused connect mask: the bytes of one "on" row (+ the first 4 again), <= 1 040
-    uint8_t  onb[260];       // fused masks: row q = (source, target) is on
+struct ObsStage {            // carved out of dynamic shared memory, sized for the topology at launch (obs_stage_bytes)
+    uint64_t* props;         // [N]  discovered properties of the node at external index i
+    uint32_t* lmask;         // [N]  its local-vulnerability mask (static)
+    uint4*    pat;           // [65] fused connect mask: the bytes of one "on" row (+ the first 4 again), <= 1 040
+    uint8_t*  ext_of;        // [N]  node id -> external index
+    uint8_t*  priv;          // [N]  privilege level of the node at external index i
+    uint8_t*  cred_node;     // [T]  node id of cached credential r
+    uint8_t*  cred_port;     // [T]  port index of cached credential r
+    uint8_t*  onb;           // [260] fused masks: row q = (source, target) is on
 };
+__host__ __device__ inline uint32_t obs_stage_bytes(uint32_t n_nodes, uint32_t n_triples) {   // per wavefront, multiple of 16
+    const uint32_t N = (n_nodes + 15u) & ~15u, T = (n_triples + 16u) & ~15u;
+    return 8u * N + 4u * N + 1040u + N + N + T + T + 272u;
+}
+__device__ __forceinline__ ObsStage obs_stage_at(uint8_t* base, uint32_t n_nodes, uint32_t n_triples) {
+    const uint32_t N = (n_nodes + 15u) & ~15u, T = (n_triples + 16u) & ~15u;
+    ObsStage s;
+    s.props = reinterpret_cast<uint64_t*>(base); base += 8u * N;
+    s.lmask = reinterpret_cast<uint32_t*>(base); base += 4u * N;
+    s.pat = reinterpret_cast<uint4*>(base); base += 1040u;
+    s.ext_of = base; base += N;
+    s.priv = base; base += N;
+    s.cred_node = base; base += T;
+    s.cred_port = base; base += T;
+    s.onb = base;
+    return s;
+}
 
 // Structure: ALL loads first, then ALL stores.  On gfx9 loads and stores share the vmcnt counter and retire in order, so a
 // load issued after a store waits for that store's write acknowledgement; a first version that interleaved "load what this
@@ -45,12 +62,13 @@ struct ObsStage {
 // header; the two lists; rows / static tables), parks it in LDS by external index, and the rest of the kernel only computes
 // from LDS and streams stores.
 __global__ __launch_bounds__(256) void obs_small_kernel(DevState S, Topo T, StepCfg C, ObsIO O, ObsDigest* digest) {
-    __shared__ ObsStage stage_all[4];
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    extern __shared__ uint4 obs_lds[];
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;   // wave index as a scalar
     const uint32_t e = blockIdx.x * 4u + wave;
     if (e >= S.E) return;                     // whole wavefront leaves together
     if (O.env_mask && !O.env_mask[e]) return; // wave-uniform: one wavefront per env
-    ObsStage& st = stage_all[wave];
+    const uint32_t n_triples_all = T.H().n_triples;
+    const ObsStage st = obs_stage_at(reinterpret_cast<uint8_t*>(obs_lds) + wave * obs_stage_bytes(S.N, n_triples_all), S.N, n_triples_all);
     const uint4 h0 = S.h0[e];
     const uint32_t flags = h0.y, n_disc = h0.z & 0xFFFFu, n_creds = h0.z >> 16;
     if (!O.masks_only && (flags & F_SKIP)) return;   // split step, skip action: the env's previous observation stands
@@ -81,11 +99,11 @@ __global__ __launch_bounds__(256) void obs_small_kernel(DevState S, Topo T, Step
             }
             own_ext[c] = __ballot(own);
         }
-        if (c * 64u < n_creds && i < n_creds) {
-            const mcbs_triple t = TR[cl[i]];
-            st.cred_node[i] = (uint8_t)t.node;
-            st.cred_port[i] = (uint8_t)t.port;
-        }
+    }
+    for (uint32_t i = lane; i < n_creds; i += 64u) {
+        const mcbs_triple t = TR[cl[i]];
+        st.cred_node[i] = (uint8_t)t.node;
+        st.cred_port[i] = (uint8_t)t.port;
     }
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();

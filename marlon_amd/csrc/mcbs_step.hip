@@ -133,6 +133,9 @@ struct Lane {
     // result of the attacker's action
     double raw;
     int okind, olevel, new_nodes, new_creds;
+    // wide cached-triple set (DevState::cach): this lane's LDS column, [word * wide_stride], staged around a credential leak
+    uint64_t* wide_lds = nullptr;
+    uint32_t wide_stride = 0;
 
     __device__ __forceinline__ const HotNode* NS(uint32_t n) const { return reinterpret_cast<const HotNode*>(tb + C.hot_node) + n; }
     __device__ __forceinline__ Row* row(uint32_t n) const { return reinterpret_cast<Row*>(body + S.off_rows) + n; }
@@ -155,6 +158,7 @@ struct Lane {
     //   raw_nx : the raw reward when !X (0 out of bounds, -1 credential index outside the cache; env.py:736-737)
     //   kind   : 0 local, 1 remote, 2 connect; `col` = vulnerability column (exploits; 0 for connect),
     //            `port` / `triple` = connect arguments (0 for exploits).  Every index is valid for every lane.
+    template <bool WIDE_OK>      // WIDE_OK = false: the batch cannot have a wide cached-triple set (packed layout); compiles its handling out
     __device__ __forceinline__ void act(bool X, double raw_nx, int kind, uint32_t src, uint32_t tgt, uint32_t col, uint32_t port, uint32_t triple) {
         const bool k2 = kind == 2;
         // ---- look-ups of both flavours (LDS) ----
@@ -238,6 +242,10 @@ struct Lane {
         const uint32_t cnt = (xb & (creds | (vk == MCBS_OUT_LEAKED_NODES))) ? (d1.y & 0xFFFFu) : 0u;
         const uint2* pl = reinterpret_cast<const uint2*>(tb + C.hot_payload) + d1.x;
         uint32_t nn = 0, nc = 0, ncache = 0;
+        const bool wide = WIDE_OK && S.wide != 0u;       // uniform: the cached-triple set lives in memory, staged in LDS for the loop
+        const bool stage = wide && cnt != 0u && creds;
+        if (stage)
+            for (uint32_t w = 0; w < S.TW; ++w) wide_lds[w * wide_stride] = S.cach[(size_t)w * S.E + e];
         for (uint32_t i = 0; i < cnt; ++i) {
             const uint2 p = pl[i];                       // {node | cred << 16, triple | port << 16}
             const uint32_t pn = p.x & 0xFFFFu, pc = p.x >> 16, pt = p.y & 0xFFFFu;
@@ -245,15 +253,23 @@ struct Lane {
             // the count only advances for a new element, so a stale write is overwritten or never read
             const bool new_n = !rget<WT>(m[M_DISC], pn);
             const bool new_g = creds & !rget<WT>(m[M_GATH], pc);
-            const bool new_c = creds & !rget<WT>(m[M_CACH], pt);
+            bool new_c;
+            if (wide) {
+                uint64_t* w = wide_lds + (pt >> 6) * wide_stride;
+                const uint64_t old = stage ? *w : 0ull, bit = 1ull << (pt & 63u);
+                new_c = creds & !(old & bit);
+                if (stage) *w = old | bit;
+            } else new_c = creds & !rget<WT>(m[M_CACH], pt);
             disc_list()[n_disc] = (uint8_t)pn;
             cred_list()[n_creds] = (uint16_t)pt;
             uint64_t b0[WT], b1[WT], b2[WT];
-            rbit<WT>(b0, pn, new_n); rbit<WT>(b1, pc, new_g); rbit<WT>(b2, pt, new_c);
+            rbit<WT>(b0, pn, new_n); rbit<WT>(b1, pc, new_g); rbit<WT>(b2, pt & (WT * 64u - 1u), new_c && !wide);
 #pragma unroll
             for (int w = 0; w < WT; ++w) { m[M_DISC][w] |= b0[w]; m[M_GATH][w] |= b1[w]; m[M_CACH][w] |= b2[w]; }
             n_disc += new_n; nn += new_n; nc += new_g; n_creds += new_c; ncache += new_c;
         }
+        if (stage)
+            for (uint32_t w = 0; w < S.TW; ++w) S.cach[(size_t)w * S.E + e] = wide_lds[w * wide_stride];
         rx += 5 * (int)nn + 3 * (int)nc;
         const double x_raw = (double)rx - __hiloint2double((int)d0.y, (int)d0.x);
         const double c_raw = already ? -1.0 : (double)r;                                       // REPEAT, else the node's value the first time
@@ -432,6 +448,10 @@ __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, const Ste
     for (int k = 0; k < M_COUNT; ++k)
 #pragma unroll
         for (int w = 0; w < WT; ++w) ln.m[k][w] = m0[k][w];
+    if (!PK && S.wide) {                                // this lane's LDS column for the wide cached-triple set, behind the hot image
+        ln.wide_lds = reinterpret_cast<uint64_t*>(topo_lds + (TOPO_LDS ? C.hot_bytes / 16u : 0u)) + threadIdx.x;
+        ln.wide_stride = blockDim.x;
+    }
     // level 2 (needs the header): this defender tick's ring slot
     uint64_t back[WT];
 #pragma unroll
@@ -474,7 +494,7 @@ __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, const Ste
         ln.props = pt & ROW_PROPS_MASK; ln.tags = (uint32_t)(pt >> 60);
         ln.ever = r0.z; ln.since = r0.w;
         STAMP(3);  // row landed
-        ln.act(X, skip ? -1.0 : 0.0, kind, src, tgt, X ? (k0 ? a2 : (k1 ? cL + a3 : 0u)) : 0u, (X & k2) ? a3 : 0u, triple);
+        ln.template act<!PK>(X, skip ? -1.0 : 0.0, kind, src, tgt, X ? (k0 ? a2 : (k1 ? cL + a3 : 0u)) : 0u, (X & k2) ? a3 : 0u, triple);
         // unchanged rows are written back as they were
         if (PK) reinterpret_cast<uint32_t*>(body + S.off_rows)[tgt] = S.tiny_pack(ln.props, ln.tags, ln.ever, ln.since);
         else {

@@ -36,7 +36,7 @@ ABI_VERSION = 1
 TOPO_MAGIC = 0x5442434D
 
 MAX_NODES, MAX_PORTS, MAX_PROPS, MAX_SLOTS, MAX_LOCAL = 256, 32, 60, 32, 32
-MAX_CRED_STRINGS, MAX_TRIPLES = 256, 256
+MAX_CRED_STRINGS, MAX_TRIPLES = 256, 1024
 
 OUT_NONE, OUT_LEAKED_CREDENTIALS, OUT_LEAKED_NODES, OUT_PRIVILEGE_ESCALATION, OUT_LATERAL_MOVE, \
     OUT_CUSTOMER_DATA, OUT_PROBE_SUCCEEDED, OUT_PROBE_FAILED, OUT_EXPLOIT_FAILED, OUT_OTHER = range(10)

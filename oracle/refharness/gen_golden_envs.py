@@ -47,6 +47,8 @@ def main():
         "tinyad": tiny_ad.new_environment,
         "ad0": lambda: generate_ad.new_random_environment(0),
         "ad2": lambda: generate_ad.new_random_environment(2),
+        "ad1": lambda: generate_ad.new_random_environment(1),      # 365 leakable credentials: the wide cached-credential set
+        "ad6": lambda: generate_ad.new_random_environment(6),      # 821, the largest of ActiveDirectory-v0..v9
         "random_s1": lambda: ref_random_environment(1),     # its entry node has no outgoing traffic: no vulnerability at all (blob only)
         "random_s4": lambda: ref_random_environment(4),
         "random_s5": lambda: ref_random_environment(5),
@@ -110,6 +112,8 @@ def main():
     ad_case("tinyad_mix_s63", "tinyad", tiny_ad.new_environment, 63, 300, "mix", 20)
     ad_case("ad0_valid_s64", "ad0", lambda: generate_ad.new_random_environment(0), 64, 250, "valid", len(topos["ad0"].triples))
     ad_case("ad2_mix_s65", "ad2", lambda: generate_ad.new_random_environment(2), 65, 250, "mix", len(topos["ad2"].triples))
+    ad_case("ad1_valid_s69", "ad1", lambda: generate_ad.new_random_environment(1), 69, 300, "valid", len(topos["ad1"].triples))
+    ad_case("ad6_mix_s70", "ad6", lambda: generate_ad.new_random_environment(6), 70, 300, "mix", len(topos["ad6"].triples))
 
     # ---- model.assign_random_labels on a directed path, entry node at Admin privilege ----
     t = topos["labelled_s4"]

@@ -38,7 +38,7 @@ def topology_for(trace_name: str) -> F.FlatTopology:
         return F.flatten(active_directory.new_tiny_environment())
     if trace_name.startswith("tiny"):
         return F.flatten(tinytoy.new_environment())
-    if trace_name.startswith("ad0") or trace_name.startswith("ad2"):
+    if trace_name[:2] == "ad" and trace_name[2].isdigit():
         return F.flatten(active_directory.new_random_environment(int(trace_name[2])))
     if trace_name.startswith("random_s"):
         return F.flatten(generate_network.new_environment(15, seed=int(trace_name.split("_")[1][1:])))

@@ -36,7 +36,7 @@ def _env_for(name, sj, **kw):
         return ce.CyberBattleToyCtf(**common)
     if name.startswith("tiny_"):
         return ce.CyberBattleTiny(**common)
-    if name.startswith("ad0") or name.startswith("ad2"):
+    if name[:2] == "ad" and name[2].isdigit():
         return ce.CyberBattleActiveDirectory(seed=int(name[2]), **common)
     if name.startswith("random_s"):
         return ce.CyberBattleRandom(seed=int(name.split("_")[1][1:]), **common)
@@ -48,7 +48,7 @@ def _env_for(name, sj, **kw):
 VALID_TRACES = ["chain10_valid_s1", "chain10_valid_s2", "chain10_rewardgoal_s6", "toyctf_defender_s11", "toyctf_defender_s12",
                 "toyctf_slabreak_s16", "sink_evict_s44", "sink_attackerwin_s45", "chain100_defender_s31",
                 # the other registered environments, through their own facade classes (CyberBattleTiny / ActiveDirectory / Random)
-                "tiny_defender_s62", "ad0_valid_s64", "random_s4_valid_s66"]
+                "tiny_defender_s62", "ad0_valid_s64", "ad1_valid_s69", "random_s4_valid_s66"]
 
 
 @pytest.mark.parametrize("name", VALID_TRACES)

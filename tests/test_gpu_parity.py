@@ -78,6 +78,8 @@ CASES = {
     "sink_defender": ("sink_defender_s43", dict(), 2048, 300),
     "sink_evict": ("sink_evict_s44", dict(), 1024, 200),
     "random24_defender": ("random24_defender_s51", dict(), 1024, 200),
+    "ad6_wide_cache": ("ad6_mix_s70", dict(), 512, 200),          # 821 cacheable credentials: the set lives in memory / LDS
+    "random_s5_defender": ("random_s5_defender_s67", dict(), 512, 150),
 }
 
 
