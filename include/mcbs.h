@@ -115,8 +115,22 @@ typedef struct mcbs_topo_header { /* 192 bytes */
     uint32_t n_fw_lists;          /* distinct rule list objects */
     uint32_t off_fw_list0;        /* uint16[n_fw_lists]: initial state of the six manageable names in each list: bit r = a rule named r
                                      exists, bit 6+r = the first one is ALLOW */
-    uint32_t reserved[2];
+    uint32_t off_ere;             /* mcbs_ere_tables + arrays: what the ExternalRandomEvents defender needs (defender.py:58-148) */
+    uint32_t reserved;
 } mcbs_topo_header;
+
+/* Tables of the ExternalRandomEvents defender; array offsets are relative to the start of this structure.  A vulnerability
+ * "column" is its index in the identifiers: local l -> l, remote r -> n_local + r (at most 64 columns). */
+typedef struct mcbs_ere_tables { /* 40 bytes */
+    uint32_t n_library;       /* global library vulnerabilities = the first n_library slots of every node */
+    uint32_t key_cap;         /* capacity of a node's key list: the longest own list + n_library */
+    uint32_t off_own_keys;    /* uint8[n_nodes][key_cap]: the node's OWN vulnerability dictionary keys in order, as columns (0xFF pad) */
+    uint32_t off_own_cnt;     /* uint8[n_nodes] */
+    uint32_t off_lib_sorted;  /* uint8[n_library]: library columns in name order (numpy.setdiff1d returns sorted names) */
+    uint32_t pad;
+    uint64_t lib_cols;        /* bit c: column c is a library vulnerability */
+    uint8_t  sample_name[8];  /* firewall name ids of model.SAMPLE_IDENTIFIERS.ports (7 used): the ports firewall_change_add opens */
+} mcbs_ere_tables;
 
 typedef struct mcbs_node_static { /* 64 bytes */
     uint64_t props;        /* static properties that are declared identifiers (bit = index) */
@@ -178,6 +192,9 @@ typedef struct mcbs_triple { /* 8 bytes */
  * ================================================================================ */
 #define MCBS_DEFENDER_NONE 0
 #define MCBS_DEFENDER_SCAN_AND_REIMAGE 1 /* ScanAndReimageCompromisedMachines */
+#define MCBS_FW_GROWTH 120             /* ExternalRandomEvents: rules a list may gain beyond its initial length before the overflow flag */
+#define MCBS_DEFENDER_RANDOM_EVENTS 3    /* ExternalRandomEvents (defender.py:58-148): random patching / planting of vulnerabilities,
+                                           service stops and firewall edits, every step, on every node */
 #define MCBS_DEFENDER_EXTERNAL 2         /* no in-env defender; a learned defender acts through mcbs_defender_step
                                            (marlon: DefenderEnvWrapper + LearningDefender) */
 

@@ -8,7 +8,7 @@ from typing import Optional
 import numpy as np
 
 ABI_VERSION = 1
-DEFENDER_NONE, DEFENDER_SCAN_AND_REIMAGE, DEFENDER_EXTERNAL = 0, 1, 2
+DEFENDER_NONE, DEFENDER_SCAN_AND_REIMAGE, DEFENDER_EXTERNAL, DEFENDER_RANDOM_EVENTS = 0, 1, 2, 3
 RNG_PHILOX, RNG_TAPE = 0, 1
 
 
@@ -121,6 +121,10 @@ class EnvSpec:
         else:
             if self.defender[0] == "external":       # learned defender acting through mcbs_defender_step
                 c.defender_kind = DEFENDER_EXTERNAL
+                c.scan_frequency = 1
+                return self._finish(c)
+            if self.defender[0] == "random_events":  # ExternalRandomEvents (defender.py:58-148): no parameters
+                c.defender_kind = DEFENDER_RANDOM_EVENTS
                 c.scan_frequency = 1
                 return self._finish(c)
             kind, p, cap, freq = self.defender

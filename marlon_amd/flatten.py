@@ -43,6 +43,9 @@ OUT_NONE, OUT_LEAKED_CREDENTIALS, OUT_LEAKED_NODES, OUT_PRIVILEGE_ESCALATION, OU
 
 NODE_INSTALLED0, NODE_REIMAGABLE = 1, 2
 DEFENDER_RULE_NAMES = ("RDP", "SSH", "HTTPS", "HTTP", "su", "sudo")   # LearningDefender.firewall_rule_list (defender.py:24)
+SAMPLE_PORTS = ("RDP", "SSH", "SMB", "HTTP", "HTTPS", "WMI", "SQL")    # model.SAMPLE_IDENTIFIERS.ports (model.py:470), ExternalRandomEvents
+ERE_DT = np.dtype([("n_library", "<u4"), ("key_cap", "<u4"), ("off_own_keys", "<u4"), ("off_own_cnt", "<u4"), ("off_lib_sorted", "<u4"),
+                   ("pad", "<u4"), ("lib_cols", "<u8"), ("sample_name", "u1", (8,))])
 TAG_NAMES = tuple(f"privilege_{k}" for k in range(4))
 
 HEADER_DT = np.dtype([
@@ -56,7 +59,7 @@ HEADER_DT = np.dtype([
     ("off_service", "<u4"), ("off_allowed", "<u4"), ("off_triple", "<u4"), ("off_code", "<u4"),
     ("off_init_order", "<u4"), ("n_init_owned", "<u4"), ("full_sum", "<f8"),
     ("off_fw_rule", "<u4"), ("n_fw_rules", "<u4"), ("off_fw_range", "<u4"), ("n_names", "<u4"),
-    ("rule_name", "u1", (8,)), ("rule_port", "u1", (8,)), ("n_fw_lists", "<u4"), ("off_fw_list0", "<u4"), ("reserved", "<u4", (2,)),
+    ("rule_name", "u1", (8,)), ("rule_port", "u1", (8,)), ("n_fw_lists", "<u4"), ("off_fw_list0", "<u4"), ("off_ere", "<u4"), ("reserved", "<u4"),
 ])
 NODE_DT = np.dtype([
     ("props", "<u8"), ("sla_weight", "<f8"), ("avail_term", "<f8"), ("value", "<i4"),
@@ -233,7 +236,7 @@ def flatten(environment) -> FlatTopology:
 
     # firewall port names: identifier ports first (same ids), then every other name a rule or the learned defender uses
     name_index: Dict[str, int] = dict(port_index)
-    for extra in list(DEFENDER_RULE_NAMES) + [r.port for _, info in nodes for r in list(info.firewall.incoming) + list(info.firewall.outgoing)]:
+    for extra in list(DEFENDER_RULE_NAMES) + list(SAMPLE_PORTS) + [r.port for _, info in nodes for r in list(info.firewall.incoming) + list(info.firewall.outgoing)]:
         name_index.setdefault(extra, len(name_index))
     if len(name_index) > 255:
         raise ValueError("too many distinct firewall port names")
@@ -383,6 +386,31 @@ def flatten(environment) -> FlatTopology:
     for (n, p, c), k in triple_index.items():
         triple_tab[k] = (node_index[n], cred_index[c], port_index[p], 0)
 
+    # tables of the ExternalRandomEvents defender (defender.py:58-148): every node's OWN vulnerability keys in dictionary order
+    # as identifier columns (a key a library entry shadows is still a key), the library's columns and their name-sorted order
+    # (numpy.setdiff1d returns sorted names), the name ids of the ports it may open
+    col_of = {vid: k for k, vid in enumerate(local_ids)}
+    col_of.update({vid: L + k for k, vid in enumerate(remote_ids)})
+    if L + R > 64:
+        raise ValueError("more than 64 vulnerability identifiers")
+    own_lists = [[col_of[vid] for vid in info.vulnerabilities] for _, info in nodes]
+    key_cap = max(1, max(len(k) for k in own_lists) + len(library))
+    own_keys = np.full((N, key_cap), 0xFF, np.uint8)
+    for i, ks in enumerate(own_lists):
+        own_keys[i, :len(ks)] = ks
+    ere = np.zeros(1, ERE_DT)
+    ere["n_library"], ere["key_cap"] = len(library), key_cap
+    ere["lib_cols"] = sum(1 << col_of[vid] for vid in library)
+    ere["sample_name"][0, :7] = [name_index[p] for p in SAMPLE_PORTS]
+    ere_base = ERE_DT.itemsize
+    ere_arrays = [("off_own_keys", own_keys.tobytes()), ("off_own_cnt", np.array([len(k) for k in own_lists], np.uint8).tobytes()),
+                  ("off_lib_sorted", np.array([col_of[vid] for vid in sorted(library)], np.uint8).tobytes())]
+    ere_body = bytearray()
+    for field, data in ere_arrays:                     # offsets relative to the start of the section
+        ere_body += b"\0" * ((-(ere_base + len(ere_body))) % 4)
+        ere[field] = ere_base + len(ere_body)
+        ere_body += data
+
     sections = [
         ("node", node_tab.tobytes()), ("slot_of", slot_of.tobytes()), ("slot", slot_tab.tobytes()),
         ("payload", payload_tab.tobytes()), ("service", service_tab.tobytes()),
@@ -390,6 +418,7 @@ def flatten(environment) -> FlatTopology:
         ("code", bytes(code)), ("init_order", init_order.tobytes()),
         ("fw_rule", np.array(fw_rules, np.uint8).reshape(-1, 2).tobytes()), ("fw_range", np.array(fw_range, np.uint16).reshape(-1, 2).tobytes()),
         ("fw_list0", np.array(fw_list0, np.uint16).tobytes()),
+        ("ere", ere.tobytes() + bytes(ere_body)),
     ]
     hdr = np.zeros(1, HEADER_DT)
     h = hdr[0]

@@ -67,7 +67,11 @@ typedef struct {
     int* gathered;                       /* AgentActions._gathered_credentials, by credential-string id */
     /* the firewall rule list objects (model.py:275-305), mutable by the learned defender; a node's incoming / outgoing
      * list is looked up by id because several nodes / directions may hold the SAME list object */
-    mcbs_fw_rule** fwl; int* n_fwl;
+    mcbs_fw_rule** fwl; int* n_fwl; int* cap_fwl;
+    /* ExternalRandomEvents (defender.py:58-148) mutates these per env: every node's own vulnerability dictionary (keys as
+     * identifier columns, in insertion order) and the running flag of every service */
+    uint8_t* keys; uint8_t* kcnt; uint8_t* svc_running;
+    int fw_overflow;                     /* a rule list hit its capacity: parity with the reference is lost from here on */
     int64_t clock;
     int stepcount, done, truncated, episode;
     double episode_reward_sum;           /* numpy.sum(__episode_rewards): rewards are exact integers or one rounded
@@ -90,6 +94,7 @@ typedef struct {
     const uint8_t* CODE;
     const mcbs_fw_rule* FWR;
     const uint16_t* FWRANGE;
+    const mcbs_ere_tables* ERE; const uint8_t* own_keys; const uint8_t* own_cnt; const uint8_t* lib_sorted;
     mcbs_batch_cfg cfg;
     int n_envs;
     oenv* env;
@@ -185,6 +190,19 @@ static void mark_node_as_owned(const oracle* o, oenv* e, int n, int privilege, i
     }
 }
 
+/* is_global_vulnerability or is_inplace_vulnerability (actions.py:339-351) on the env's CURRENT dictionaries: only the
+ * ExternalRandomEvents defender changes them, otherwise the static slot table says it all */
+static int random_events(const oracle* o) { return o->cfg.defender_kind == MCBS_DEFENDER_RANDOM_EVENTS; }
+static int has_key(const oracle* o, const oenv* e, int node, int col) {
+    const uint8_t* k = e->keys + (size_t)node * o->ERE->key_cap;
+    for (int i = 0; i < e->kcnt[node]; ++i) if (k[i] == col) return 1;
+    return 0;
+}
+static int vulnerability_present(const oracle* o, const oenv* e, int node, int col) {
+    if (!random_events(o)) return 1;
+    return ((o->ERE->lib_cols >> col) & 1u) || has_key(o, e, node, col);
+}
+
 typedef struct { double reward; int kind; int level; int slot_node; const mcbs_vuln_slot* v; } action_result;
 static action_result result(double r, int kind) { action_result a; a.reward = r; a.kind = kind; a.level = 0; a.slot_node = -1; a.v = NULL; return a; }
 
@@ -193,7 +211,7 @@ static int process_outcome(const oracle* o, oenv* e, int vuln_col, int node, dou
     onode* x = &e->node[node];
     if (x->status != ST_RUNNING) { *out = result(P_MACHINE_NOT_RUNNING, MCBS_OUT_NONE); return 0; }
     int s = o->slot_of[(size_t)node * (o->H->n_local + o->H->n_remote) + vuln_col];
-    if (s == 0xFF) { *out = result(P_SUSPICIOUSNESS, MCBS_OUT_NONE); return 0; }
+    if (s == 0xFF || !vulnerability_present(o, e, node, vuln_col)) { *out = result(P_SUSPICIOUSNESS, MCBS_OUT_NONE); return 0; }
     const mcbs_vuln_slot* v = slot(o, node, s);
     if (!check_prerequisites(o, e, node, v)) { *out = result(failed_penalty, MCBS_OUT_EXPLOIT_FAILED); return 0; }
 
@@ -257,11 +275,12 @@ static action_result exploit_remote(const oracle* o, oenv* e, int source, int ta
 }
 
 /* _check_service_running_and_authorized (actions.py:608-621) */
-static int service_running_and_authorized(const oracle* o, int target, int port, int cred) {
+static int service_is_running(const oracle* o, const oenv* e, int svc) { return random_events(o) ? e->svc_running[svc] : (o->SV[svc].running ? 1 : 0); }
+static int service_running_and_authorized(const oracle* o, const oenv* e, int target, int port, int cred) {
     const mcbs_node_static* t = &o->NS[target];
     for (int i = 0; i < t->svc_cnt; ++i) {
         const mcbs_service* sv = &o->SV[t->svc_off + i];
-        if (!sv->running || sv->port != port) continue;
+        if (!service_is_running(o, e, t->svc_off + i) || sv->port != port) continue;
         for (int k = 0; k < sv->allowed_cnt; ++k) if (o->AL[sv->allowed_off + k] == cred) return 1;
     }
     return 0;
@@ -287,7 +306,7 @@ static action_result connect_to_remote_machine(const oracle* o, oenv* e, int sou
     for (int i = 0; i < o->NS[target].svc_cnt; ++i) if (o->SV[o->NS[target].svc_off + i].port == port) listening = 1;
     if (!listening) return result(P_SCANNING_UNOPEN_PORT, MCBS_OUT_NONE);
     if (e->node[target].status != ST_RUNNING) return result(P_MACHINE_NOT_RUNNING, MCBS_OUT_NONE);
-    if (!service_running_and_authorized(o, target, port, cred)) return result(P_WRONG_PASSWORD, MCBS_OUT_NONE);
+    if (!service_running_and_authorized(o, e, target, port, cred)) return result(P_WRONG_PASSWORD, MCBS_OUT_NONE);
     int64_t last; int already;
     mark_node_as_owned(o, e, target, 1, &last, &already);
     if (already) return result(P_REPEAT, MCBS_OUT_LATERAL_MOVE);
@@ -319,7 +338,7 @@ static void on_attacker_step_taken(const oracle* o, oenv* e) {
         for (int i = 0; i < t->svc_cnt; ++i) {
             const mcbs_service* sv = &o->SV[t->svc_off + i];
             total_service_weights += sv->sla_weight;
-            running_service_weights += sv->sla_weight * (sv->running ? 1 : 0);
+            running_service_weights += sv->sla_weight * service_is_running(o, e, t->svc_off + i);
         }
         double adjusted = (e->node[n].status == ST_RUNNING) ? (1 + running_service_weights) / (1 + total_service_weights) : 0.0;
         total_node_weights += t->sla_weight;
@@ -348,6 +367,70 @@ static void defender_step(const oracle* o, oenv* e, draws* d) {
     free(scanned);
 }
 
+/* ExternalRandomEvents.step (defender.py:61-66): five passes over every node, each node drawing numpy.random.random() <= 0.1
+ * and, when it fires, random.choice(seq) = seq[floor(random() * len(seq))] (the harness patches both generators so that the
+ * reference consumes the same doubles).  Rules compare equal on (port, permission). */
+static int pick(draws* d, int n) { int i = (int)floor(next_draw(d) * (double)n); return i < n ? i : n - 1; }
+static int rule_index(const oenv* e, int l, int name, int allow) {
+    for (int i = 0; i < e->n_fwl[l]; ++i) if (e->fwl[l][i].name == name && (e->fwl[l][i].allow ? 1 : 0) == allow) return i;
+    return -1;
+}
+static void remove_random_rule(oenv* e, int l, draws* d) {   /* rule = random.choice(list); list.remove(rule): the FIRST equal one goes */
+    int c = pick(d, e->n_fwl[l]);
+    int i = rule_index(e, l, e->fwl[l][c].name, e->fwl[l][c].allow ? 1 : 0);
+    memmove(&e->fwl[l][i], &e->fwl[l][i + 1], sizeof(mcbs_fw_rule) * (size_t)(e->n_fwl[l] - i - 1));
+    e->n_fwl[l] -= 1;
+}
+static void random_events_step(const oracle* o, oenv* e, draws* d) {
+    const double p = 0.1;
+    int N = (int)o->H->n_nodes, cap = (int)o->ERE->key_cap;
+    for (int n = 0; n < N; ++n) {                                  /* patch_vulnerabilities_at_random (:68-75) */
+        int fire = next_draw(d) <= p;
+        if (fire && e->kcnt[n] > 0) {
+            uint8_t* k = e->keys + (size_t)n * cap;
+            int c = pick(d, e->kcnt[n]);
+            memmove(k + c, k + c + 1, (size_t)(e->kcnt[n] - c - 1));
+            e->kcnt[n] -= 1;
+        }
+    }
+    for (int n = 0; n < N; ++n) {                                  /* stop_service_at_random (:77-82), stop_service (actions.py:782-787) */
+        int fire = next_draw(d) <= p;
+        const mcbs_node_static* t = &o->NS[n];
+        if (fire && t->svc_cnt > 0) {
+            int port = o->SV[t->svc_off + pick(d, t->svc_cnt)].port;
+            for (int i = 0; i < t->svc_cnt; ++i) if (o->SV[t->svc_off + i].port == port) e->svc_running[t->svc_off + i] = 0;
+        }
+    }
+    for (int n = 0; n < N; ++n) {                                  /* plant_vulnerabilities_at_random (:84-93) */
+        int fire = next_draw(d) <= p, n_new = 0;
+        uint8_t fresh[64];
+        for (uint32_t i = 0; i < o->ERE->n_library; ++i) if (!has_key(o, e, n, o->lib_sorted[i])) fresh[n_new++] = o->lib_sorted[i];
+        if (fire && n_new > 0) {
+            int col = fresh[pick(d, n_new)];
+            e->keys[(size_t)n * cap + e->kcnt[n]] = (uint8_t)col;
+            e->kcnt[n] += 1;
+        }
+    }
+    for (int n = 0; n < N; ++n) {                                  /* firewall_change_remove (:111-132) */
+        int fire = next_draw(d) <= p, lin = list_of(o, n, 0), lout = list_of(o, n, 1);
+        if (fire && e->n_fwl[lout] > 0 && e->n_fwl[lin] > 0) {
+            int incoming = next_draw(d) <= 0.5;
+            remove_random_rule(e, incoming ? lin : lout, d);
+        } else if (fire && e->n_fwl[lout] > 0) remove_random_rule(e, lout, d);
+        else if (fire && e->n_fwl[lin] > 0) remove_random_rule(e, lin, d);
+    }
+    for (int n = 0; n < N; ++n) {                                  /* firewall_change_add (:134-148) */
+        int fire = next_draw(d) <= p;
+        if (!fire) continue;
+        int name = o->ERE->sample_name[pick(d, 7)];
+        int incoming = next_draw(d) <= 0.5, lin = list_of(o, n, 0), lout = list_of(o, n, 1);
+        if (rule_index(e, lin, name, 1) >= 0) continue;            /* both branches test the INCOMING list (:145-148) */
+        int l = incoming ? lin : lout;
+        if (e->n_fwl[l] >= e->cap_fwl[l]) { e->fw_overflow = 1; continue; }
+        e->fwl[l][e->n_fwl[l]].name = (uint8_t)name; e->fwl[l][e->n_fwl[l]].allow = 1; e->n_fwl[l] += 1;
+    }
+}
+
 /* ---------------- env level ---------------- */
 static int find_external_index(const oenv* e, int node) { /* __find_external_index (env.py:603-605) */
     for (int i = 0; i < e->n_discovered; ++i) if (e->discovered[i] == node) return i;
@@ -370,6 +453,12 @@ static void reset_env(const oracle* o, oenv* e) { /* __reset_environment (env.py
         e->n_fwl[l] = o->FWRANGE[l * 2 + 1];
         memcpy(e->fwl[l], o->FWR + o->FWRANGE[l * 2], sizeof(mcbs_fw_rule) * (size_t)e->n_fwl[l]);
     }
+    if (o->ERE) {
+        memcpy(e->keys, o->own_keys, (size_t)N * o->ERE->key_cap);
+        memcpy(e->kcnt, o->own_cnt, (size_t)N);
+    }
+    for (uint32_t k = 0; k < o->H->n_services; ++k) e->svc_running[k] = o->SV[k].running ? 1 : 0;
+    e->fw_overflow = 0;
     for (int n = 0; n < N; ++n) {
         onode* x = &e->node[n];
         memset(x, 0, sizeof(*x));
@@ -398,7 +487,8 @@ static void update_action_mask(const oracle* o, const oenv* e, const oobs* b) { 
     for (int si = 0; si < e->n_discovered; ++si) {
         int src = e->discovered[si];
         if (!e->node[src].agent_installed) continue;
-        if (b->mask_local) for (int l = 0; l < L; ++l) if ((o->NS[src].local_mask >> l) & 1u) b->mask_local[si * L + l] = 1;
+        if (b->mask_local) for (int l = 0; l < L; ++l)
+            if (random_events(o) ? vulnerability_present(o, e, src, l) : (int)((o->NS[src].local_mask >> l) & 1u)) b->mask_local[si * L + l] = 1;
         for (int ti = 0; ti < e->n_discovered; ++ti) {
             if (b->mask_remote) for (int r = 0; r < R; ++r) b->mask_remote[((size_t)si * Nm + ti) * R + r] = 1;
             if (b->mask_connect) for (int p = 0; p < P; ++p) for (int c = 0; c < e->n_cache && c < C; ++c)
@@ -508,13 +598,14 @@ static int step_env(const oracle* o, oenv* e, uint64_t env_gid, const int32_t a[
         }
         if (obs) write_observation(o, e, obs, 0, 0, cache_before);
         reward = r.reward;
-        if (o->cfg.defender_kind == MCBS_DEFENDER_SCAN_AND_REIMAGE) {
+        if (o->cfg.defender_kind == MCBS_DEFENDER_SCAN_AND_REIMAGE || random_events(o)) {
             draws d = { o, e, env_gid, tape, tape_len, 0 };
             on_attacker_step_taken(o, e);
-            defender_step(o, e, &d);
+            if (random_events(o)) random_events_step(o, e, &d);
+            else defender_step(o, e, &d);
         }
         /* goals (env.py:1080-1116,1162-1169) */
-        int owned = owned_count(o, e), N = (int)o->H->n_nodes, has_def = o->cfg.defender_kind == MCBS_DEFENDER_SCAN_AND_REIMAGE;
+        int owned = owned_count(o, e), N = (int)o->H->n_nodes, has_def = o->cfg.defender_kind == MCBS_DEFENDER_SCAN_AND_REIMAGE || random_events(o);
         int attacker_goal = 0;
         if (o->cfg.has_attacker_goal) {
             attacker_goal = 1;
@@ -627,6 +718,11 @@ void* cbo_create(const void* blob, size_t nbytes, const mcbs_batch_cfg* cfg) {
     o->CODE = o->blob + o->H->off_code;
     o->FWR = (const mcbs_fw_rule*)(o->blob + o->H->off_fw_rule);
     o->FWRANGE = (const uint16_t*)(o->blob + o->H->off_fw_range);
+    o->ERE = o->H->off_ere ? (const mcbs_ere_tables*)(o->blob + o->H->off_ere) : NULL;
+    if (o->ERE) {
+        const uint8_t* eb = (const uint8_t*)o->ERE;
+        o->own_keys = eb + o->ERE->off_own_keys; o->own_cnt = eb + o->ERE->off_own_cnt; o->lib_sorted = eb + o->ERE->off_lib_sorted;
+    }
     o->cfg = *cfg;
     o->n_envs = (int)cfg->n_envs;
     o->env = (oenv*)calloc((size_t)o->n_envs, sizeof(oenv));
@@ -636,8 +732,15 @@ void* cbo_create(const void* blob, size_t nbytes, const mcbs_batch_cfg* cfg) {
         e->node = (onode*)calloc((size_t)N, sizeof(onode));
         e->fwl = (mcbs_fw_rule**)calloc((size_t)o->H->n_fw_lists + 1, sizeof(mcbs_fw_rule*));
         e->n_fwl = (int*)calloc((size_t)o->H->n_fw_lists + 1, sizeof(int));
-        for (uint32_t l = 0; l < o->H->n_fw_lists; ++l)          /* room for every rule the learned defender can append */
-            e->fwl[l] = (mcbs_fw_rule*)calloc((size_t)o->FWRANGE[l * 2 + 1] + 16u * N + 64, sizeof(mcbs_fw_rule));
+        e->cap_fwl = (int*)calloc((size_t)o->H->n_fw_lists + 1, sizeof(int));
+        for (uint32_t l = 0; l < o->H->n_fw_lists; ++l) {        /* room for every rule the learned defender can append; the random-events
+                                                                    defender's capacity is the engine's: initial + MCBS_FW_GROWTH */
+            e->cap_fwl[l] = (int)o->FWRANGE[l * 2 + 1] + (cfg->defender_kind == MCBS_DEFENDER_RANDOM_EVENTS ? MCBS_FW_GROWTH : 16 * N + 64);
+            e->fwl[l] = (mcbs_fw_rule*)calloc((size_t)e->cap_fwl[l] + 1, sizeof(mcbs_fw_rule));
+        }
+        e->keys = (uint8_t*)calloc((size_t)N * (o->ERE ? o->ERE->key_cap : 1) + 1, 1);
+        e->kcnt = (uint8_t*)calloc((size_t)N + 1, 1);
+        e->svc_running = (uint8_t*)calloc((size_t)o->H->n_services + 1, 1);
         e->tracked_order = (int*)calloc((size_t)N, sizeof(int));
         e->discovered = (int*)calloc((size_t)N, sizeof(int));
         e->cache = (int*)calloc((size_t)o->H->n_triples + 1, sizeof(int));
@@ -653,7 +756,7 @@ void cbo_destroy(void* h) {
     if (!o) return;
     for (int i = 0; i < o->n_envs; ++i) {
         for (uint32_t l = 0; l < o->H->n_fw_lists; ++l) free(o->env[i].fwl[l]);
-        free(o->env[i].fwl); free(o->env[i].n_fwl);
+        free(o->env[i].fwl); free(o->env[i].n_fwl); free(o->env[i].cap_fwl); free(o->env[i].keys); free(o->env[i].kcnt); free(o->env[i].svc_running);
         free(o->env[i].node); free(o->env[i].tracked_order); free(o->env[i].discovered); free(o->env[i].cache); free(o->env[i].gathered);
     }
     free(o->env); free(o->blob); free(o);

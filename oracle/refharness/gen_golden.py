@@ -62,6 +62,14 @@ class Tape:
         n = len(population) + 0.0
         return [population[math.floor(self.next() * n)] for _ in range(k)]
 
+    # random.choice(seq) restated as seq[floor(random() * len(seq))] (ExternalRandomEvents, defender.py:74,81,92,...); CPython's own
+    # choice() draws through getrandbits, which a tape of doubles cannot feed: the patched module sees this definition instead
+    def choice(self, seq):
+        n = len(seq)
+        return seq[min(int(math.floor(self.next() * n)), n - 1)]
+
+    setdiff1d = staticmethod(np.setdiff1d)      # the defender module reaches numpy.setdiff1d through the same (rebound) global
+
     class _NpRandom:
         def __init__(self, tape):
             self.tape = tape

@@ -121,6 +121,22 @@ def main():
                                                    maximum_node_count=6, throws_on_invalid_actions=False),
                 t, 200, "mix", 68, spec(6, 3, 5))
 
+    # ---- ExternalRandomEvents (defender.py:58-148) on ToyCtf, Chain-4 and the kitchen sink (library vulnerabilities to plant):
+    # vulnerabilities patched / planted, services stopped, firewall rules removed / added, every step, on every node ----
+    ERE = ref.defender.ExternalRandomEvents
+    from marlon_amd.samples import kitchen_sink as ks
+    for name, key, make, N, C, seed, steps, sla in (
+            ("toyctf_randomevents_s81", "toyctf", ref.toy_ctf.new_environment, 12, 10, 81, 400, 0.5),
+            ("chain4_randomevents_s82", "chain4", lambda: ref.chainpattern.new_environment(4), 6, 6, 82, 400, 0.0),
+            ("sink_randomevents_s83", "sink", lambda: ks.build(ref.model), None, None, 83, 400, 0.4)):
+        t = F.flatten(make())
+        N = N or t.n_nodes
+        C = C or max(1, len(t.triples))
+        G.run_trace(name, lambda make=make, N=N, C=C, sla=sla: Env(make(), attacker_goal=AG(own_atleast_percent=1.0), defender_agent=ERE(),
+                                                                   defender_constraint=DC(maintain_sla=sla), maximum_total_credentials=C,
+                                                                   maximum_node_count=N, throws_on_invalid_actions=False),
+                    t, steps, "mix", seed, spec(N, C, 5, defender=["random_events"], maintain_sla=sla), tape_dps=12 * t.n_nodes + 8)
+
     # ---- random traffic network (CyberBattleRandom-v0's generator, seeded), attacker only and with a defender ----
     t = topos["random_s4"]
     N, C = t.n_nodes, len(t.triples)

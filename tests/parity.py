@@ -67,7 +67,7 @@ def spec_from_json(spec: dict, n_envs: int = 1, auto_reset: bool = True, **over)
         maximum_discoverable_credentials_per_action=spec["maximum_discoverable_credentials_per_action"],
         attacker_goal=spec["attacker_goal"], maintain_sla=spec["maintain_sla"],
         winning_reward=spec["winning_reward"], losing_reward=spec["losing_reward"],
-        defender=None if d is None else (d[0], d[1], d[2], d[3]),
+        defender=None if d is None else tuple(d),
         auto_reset=auto_reset, rng_kind=RNG_TAPE)
     kw.update(over)
     return EnvSpec(**kw)
