@@ -53,6 +53,7 @@ struct mcbs_batch {
     Topo T{};
     StepCfg C{};
     StepCfg* C_dev = nullptr;       // device copy read by the step kernel through the scalar cache
+    uint32_t* ere_lists_dev = nullptr;
     uint8_t* arena = nullptr;       // every per-env column + bodies + init body, one allocation
     size_t arena_bytes = 0;
     ObsDigest* digest = nullptr;
@@ -235,7 +236,9 @@ extern "C" int mcbs_batch_create(const mcbs_topology* topo, const mcbs_batch_cfg
         return fail(MCBS_ELIMIT, "the topology can leak %u distinct credentials but maximum_total_credentials is %u "
                     "(the reference would overflow its observation space)", h->n_triples, cfg->maximum_total_credentials);
     if (cfg->maximum_discoverable_credentials_per_action > 1023u) return fail(MCBS_ELIMIT, "maximum_discoverable_credentials_per_action too large");
-    if (cfg->defender_kind > MCBS_DEFENDER_EXTERNAL) return fail(MCBS_EINVAL, "unknown defender kind");
+    if (cfg->defender_kind > MCBS_DEFENDER_RANDOM_EVENTS) return fail(MCBS_EINVAL, "unknown defender kind");
+    const bool random_events = cfg->defender_kind == MCBS_DEFENDER_RANDOM_EVENTS;
+    if (random_events && !h->off_ere) return fail(MCBS_EINVAL, "the topology blob carries no ExternalRandomEvents tables (off_ere)");
     if (cfg->defender_kind == MCBS_DEFENDER_SCAN_AND_REIMAGE && cfg->scan_frequency == 0) return fail(MCBS_EINVAL, "scan_frequency must be positive");
     if (cfg->rng_kind > MCBS_RNG_TAPE) return fail(MCBS_EINVAL, "unknown rng kind");
     if (h->n_cred_strings > MCBS_MAX_CRED_STRINGS || h->n_triples > MCBS_MAX_TRIPLES)
@@ -264,7 +267,33 @@ extern "C" int mcbs_batch_create(const mcbs_topology* topo, const mcbs_batch_cfg
                 !getenv("MCBS_NO_PACKED_SETS")) ? 1u : 0u;
     const size_t row_bytes = S.packed ? 4u : sizeof(Row);
     S.off_fw = external ? (uint32_t)align_up((size_t)S.off_rows + row_bytes * N, 16) : 0u;
-    S.body_stride = (uint32_t)align_up(external ? (size_t)S.off_fw + 2u * h->n_fw_lists : (size_t)S.off_rows + row_bytes * N, S.packed ? 16 : 64);
+    size_t body_end = external ? (size_t)S.off_fw + 2u * h->n_fw_lists : (size_t)S.off_rows + row_bytes * N;
+    // ExternalRandomEvents overlay (mcbs_ere.hip): key lists, key counts, presence masks, service bits, rule lists {count, entries}
+    StepCfg& C0 = b->C;
+    std::vector<uint32_t> ere_lists;
+    if (random_events) {
+        const mcbs_ere_tables* et = reinterpret_cast<const mcbs_ere_tables*>(topo->host.data() + h->off_ere);
+        C0.ere_key_cap = et->key_cap; C0.ere_n_library = et->n_library; C0.ere_lib_cols = et->lib_cols; C0.off_ere = h->off_ere;
+        C0.ere_off_present = (uint32_t)align_up(body_end, 8);
+        C0.ere_off_svc = C0.ere_off_present + 8u * N;
+        C0.ere_off_keys = C0.ere_off_svc + 4u * N;
+        C0.ere_off_kcnt = C0.ere_off_keys + et->key_cap * N;
+        C0.ere_off_fw = (uint32_t)align_up((size_t)C0.ere_off_kcnt + N, 2);
+        const uint16_t* fr = reinterpret_cast<const uint16_t*>(topo->host.data() + h->off_fw_range);
+        uint32_t off = 0;
+        for (uint32_t l = 0; l < h->n_fw_lists; ++l) {
+            const uint32_t cap = fr[l * 2 + 1] + MCBS_FW_GROWTH;
+            if (off > 0xFFFFu) { delete b; return fail(MCBS_ELIMIT, "firewall rule lists too large for the random-events overlay"); }
+            ere_lists.push_back(off | (cap << 16));
+            off += 2u * (1u + cap);
+        }
+        body_end = (size_t)C0.ere_off_fw + off;
+        for (uint32_t n = 0; n < N; ++n) {
+            const mcbs_node_static* nsn = reinterpret_cast<const mcbs_node_static*>(topo->host.data() + h->off_node) + n;
+            if (nsn->svc_cnt > 32) { delete b; return fail(MCBS_ELIMIT, "node %u has more than 32 services", n); }
+        }
+    }
+    S.body_stride = (uint32_t)align_up(body_end, S.packed ? 16 : 64);
 
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
@@ -308,6 +337,34 @@ extern "C" int mcbs_batch_create(const mcbs_topology* topo, const mcbs_batch_cfg
     }
     memcpy(init.data() + S.off_disc, topo->host.data() + h->off_init_order, h->n_init_owned);
     if (external) memcpy(init.data() + S.off_fw, topo->host.data() + h->off_fw_list0, 2u * h->n_fw_lists);
+    if (random_events) {
+        const uint8_t* tb = topo->host.data();
+        const mcbs_ere_tables* et = reinterpret_cast<const mcbs_ere_tables*>(tb + h->off_ere);
+        const uint8_t* own_keys = reinterpret_cast<const uint8_t*>(et) + et->off_own_keys;
+        const uint8_t* own_cnt = reinterpret_cast<const uint8_t*>(et) + et->off_own_cnt;
+        const mcbs_service* sv0 = reinterpret_cast<const mcbs_service*>(tb + h->off_service);
+        memcpy(init.data() + b->C.ere_off_keys, own_keys, (size_t)et->key_cap * N);
+        memcpy(init.data() + b->C.ere_off_kcnt, own_cnt, N);
+        for (uint32_t n = 0; n < N; ++n) {
+            uint64_t present = 0;
+            for (uint32_t k = 0; k < own_cnt[n]; ++k) present |= 1ull << own_keys[(size_t)n * et->key_cap + k];
+            memcpy(init.data() + b->C.ere_off_present + 8u * n, &present, 8);
+            uint32_t run = 0;
+            for (uint32_t i = 0; i < ns[n].svc_cnt; ++i) if (sv0[ns[n].svc_off + i].running) run |= 1u << i;
+            memcpy(init.data() + b->C.ere_off_svc + 4u * n, &run, 4);
+        }
+        const mcbs_fw_rule* fwr = reinterpret_cast<const mcbs_fw_rule*>(tb + h->off_fw_rule);
+        const uint16_t* fr = reinterpret_cast<const uint16_t*>(tb + h->off_fw_range);
+        for (uint32_t l = 0; l < h->n_fw_lists; ++l) {
+            uint16_t* L = reinterpret_cast<uint16_t*>(init.data() + b->C.ere_off_fw + (ere_lists[l] & 0xFFFFu));
+            L[0] = fr[l * 2 + 1];
+            for (uint32_t i = 0; i < fr[l * 2 + 1]; ++i) L[1 + i] = (uint16_t)(fwr[fr[l * 2] + i].name | ((fwr[fr[l * 2] + i].allow ? 1u : 0u) << 8));
+        }
+        hipError_t e2 = hipMalloc(&b->ere_lists_dev, sizeof(uint32_t) * (ere_lists.size() + 1));
+        if (e2 == hipSuccess) e2 = hipMemcpy(b->ere_lists_dev, ere_lists.data(), sizeof(uint32_t) * ere_lists.size(), hipMemcpyHostToDevice);
+        if (e2 != hipSuccess) { (void)hipFree(b->arena); delete b; return fail(MCBS_EHIP, "random-events tables upload failed: %s", hipGetErrorString(e2)); }
+        b->C.ere_lists = b->ere_lists_dev;
+    }
     e = hipMemcpy(a + o_init, init.data(), init.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(b->arena); delete b; return fail(MCBS_EHIP, "init image upload failed: %s", hipGetErrorString(e)); }
 
@@ -346,6 +403,7 @@ extern "C" void mcbs_batch_destroy(mcbs_batch* b) {
     for (hipEvent_t ev : b->ev) (void)hipEventDestroy(ev);
     if (b->arena) (void)hipFree(b->arena);
     if (b->C_dev) (void)hipFree(b->C_dev);
+    if (b->ere_lists_dev) (void)hipFree(b->ere_lists_dev);
     delete b;
 }
 
@@ -429,6 +487,7 @@ static void launch_step_v(mcbs_batch* b, const StepIO& io, hipStream_t st) {
 template <int PHASE, int WT>
 static void launch_step_nw(mcbs_batch* b, const StepIO& io, hipStream_t st) {
     if (b->cfg.defender_kind == MCBS_DEFENDER_SCAN_AND_REIMAGE) launch_step_v<PHASE, WT, MCBS_DEFENDER_SCAN_AND_REIMAGE>(b, io, st);
+    else if (b->cfg.defender_kind == MCBS_DEFENDER_RANDOM_EVENTS) launch_step_v<PHASE, WT, MCBS_DEFENDER_RANDOM_EVENTS>(b, io, st);
     else if (b->cfg.defender_kind == MCBS_DEFENDER_EXTERNAL) launch_step_v<PHASE, WT, MCBS_DEFENDER_EXTERNAL>(b, io, st);
     else launch_step_v<PHASE, WT, MCBS_DEFENDER_NONE>(b, io, st);
 }

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(128) void sample_kernel(DevState S, Topo T, StepCfg
             if (kind == 0) {
                 const uint32_t v = below(C.L);
                 a[0] = 0; a[1] = (int32_t)src; a[2] = (int32_t)v; a[3] = 0; a[4] = 0;
-                if (installed && ((NS[node].local_mask >> v) & 1u)) break;
+                if (installed && ((local_mask_of(C, NS, S.body + (size_t)e * S.body_stride, node) >> v) & 1u)) break;
             } else if (kind == 1) {
                 a[0] = 1; a[1] = (int32_t)src; a[2] = (int32_t)below(n_disc); a[3] = (int32_t)below(C.R); a[4] = 0;
                 if (installed) break;

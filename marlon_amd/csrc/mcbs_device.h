@@ -142,6 +142,15 @@ struct StepCfg {        // the parts of mcbs_batch_cfg the kernels read
     uint8_t  rule_port[8];   // identifier-port index of RDP, SSH, HTTPS, HTTP, su, sudo (0xFF: not an identifier port)
     uint32_t n_services, n_fw_lists;
     uint32_t hot_fwlist;     // uint32[N]: incoming list id | outgoing list id << 16
+    // ExternalRandomEvents (MCBS_DEFENDER_RANDOM_EVENTS): per-env overlay in the body (offsets from the env's body start) and the
+    // static tables it is edited against.  Every node's OWN vulnerability keys, in dictionary order, as identifier columns;
+    // a presence mask of those keys; the running bits of its services; every firewall rule LIST as {count, entries[cap]} of
+    // u16 (name | allow << 8) at ere_lists[l] = offset | cap << 16 (the lists are objects of their own: DESIGN.md "rule lists").
+    uint32_t ere_off_keys, ere_off_kcnt, ere_off_present, ere_off_svc, ere_off_fw, ere_key_cap, ere_n_library;
+    uint32_t off_ere;        // blob offset of mcbs_ere_tables
+    uint64_t ere_lib_cols;   // columns that are library (global) vulnerabilities: present on every node, always
+    const uint32_t* ere_lists;
+    uint32_t off_service_cold, off_allowed_cold;   // (aliases of off_service / off_allowed, kept next to their only hot-path user)
 };
 
 struct StepIO {
@@ -173,6 +182,14 @@ struct ObsIO {
     uint32_t fuse_connect; // 1: mask_connect written by obs_small_kernel (row length P*C a multiple of 16, 16-byte aligned)
     uint32_t fuse_discrete; // 1: mask_discrete (connect | local | remote per env, 4-byte granularity) written by obs_small_kernel
 };
+
+// Local-vulnerability mask of node n as the action mask sees it (env.py:653-659): static, except under ExternalRandomEvents where
+// the node's own keys change (library vulnerabilities stay visible on every node)
+__device__ __forceinline__ uint32_t local_mask_of(const StepCfg& C, const mcbs_node_static* NS, const uint8_t* body_e, uint32_t n) {
+    if (C.defender_kind != MCBS_DEFENDER_RANDOM_EVENTS) return NS[n].local_mask;
+    const uint64_t present = reinterpret_cast<const uint64_t*>(body_e + C.ere_off_present)[n] | C.ere_lib_cols;
+    return (uint32_t)present & (C.L >= 32u ? ~0u : ((1u << C.L) - 1u));
+}
 
 // ------------------------------ Philox4x32-10 (Random123) ------------------------------
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void obs_small_kernel(DevState S, Topo T, Step
                 own = S.has(M_INST, n, e);
                 st.ext_of[n] = (uint8_t)i;
                 st.props[i] = S.row_get(body, n).props_tags & ROW_PROPS_MASK;
-                st.lmask[i] = NS[n].local_mask;
+                st.lmask[i] = local_mask_of(C, NS, body, n);
                 st.priv[i] = (uint8_t)((uint32_t)S.has(M_PLO, n, e) | ((uint32_t)S.has(M_PHI, n, e) << 1));
             }
             own_ext[c] = __ballot(own);
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void mask_kernel(DevState S, Topo T, StepCfg C
     bool row_on = false;
     auto load_row = [&]() {
         row_on = s < Nm && ((d.own_ext[(s >> 6) & 3u] >> (s & 63u)) & 1ull) && (REGION == 2 || t < d.n_disc);
-        if (REGION == 2 && row_on) lmask = NS[dl[s]].local_mask;
+        if (REGION == 2 && row_on) lmask = local_mask_of(C, NS, S.body + (size_t)e * S.body_stride, dl[s]);
     };
     load_row();
     uint32_t c = REGION == 0 ? in % Cm : 0u;              // credential index inside the (source, target, port) row

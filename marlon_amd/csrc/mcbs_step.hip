@@ -47,6 +47,7 @@
 // (actions.py:517-522), see DESIGN.md "Logical time".
 #pragma once
 #include "mcbs_device.h"
+#include "mcbs_ere.hip"
 
 namespace mcbs {
 
@@ -136,6 +137,7 @@ struct Lane {
     // wide cached-triple set (DevState::cach): this lane's LDS column, [word * wide_stride], staged around a credential leak
     uint64_t* wide_lds = nullptr;
     uint32_t wide_stride = 0;
+    const uint8_t* ere_blob = nullptr;   // the topology blob (ExternalRandomEvents reads its cold tables)
 
     __device__ __forceinline__ const HotNode* NS(uint32_t n) const { return reinterpret_cast<const HotNode*>(tb + C.hot_node) + n; }
     __device__ __forceinline__ Row* row(uint32_t n) const { return reinterpret_cast<Row*>(body + S.off_rows) + n; }
@@ -158,7 +160,9 @@ struct Lane {
     //   raw_nx : the raw reward when !X (0 out of bounds, -1 credential index outside the cache; env.py:736-737)
     //   kind   : 0 local, 1 remote, 2 connect; `col` = vulnerability column (exploits; 0 for connect),
     //            `port` / `triple` = connect arguments (0 for exploits).  Every index is valid for every lane.
-    template <bool WIDE_OK>      // WIDE_OK = false: the batch cannot have a wide cached-triple set (packed layout); compiles its handling out
+    // WIDE_OK = false: the batch cannot have a wide cached-triple set (packed layout); compiles its handling out.
+    // DK: the batch's defender kind; MCBS_DEFENDER_RANDOM_EVENTS consults the env's own vulnerability / service / firewall state
+    template <bool WIDE_OK, int DK>
     __device__ __forceinline__ void act(bool X, double raw_nx, int kind, uint32_t src, uint32_t tgt, uint32_t col, uint32_t port, uint32_t triple) {
         const bool k2 = kind == 2;
         // ---- look-ups of both flavours (LDS) ----
@@ -187,14 +191,25 @@ struct Lane {
                 in_ok = mine ? (((fw_tgt >> r) & (fw_tgt >> (6u + r)) & 1u) != 0) : in_ok;     // fw_tgt: the target's INCOMING list
             }
         }
+        bool authorized = (auth >> (cred & 63u)) & 1ull;                                        // actions.py:608-621, precomputed per (node, port)
+        uint64_t own_present = ~0ull;
+        if (DK == MCBS_DEFENDER_RANDOM_EVENTS) {               // (slow path by design: loops over the env's own tables in memory)
+            const EreView V{body, C, ere_blob, S.N};
+            own_present = V.present(tgt) | C.ere_lib_cols;
+            if (X & k2) {
+                const uint32_t* lists = reinterpret_cast<const uint32_t*>(tb + C.hot_fwlist);
+                out_ok = V.passes(lists[src] >> 16, port);
+                in_ok = V.passes(lists[tgt] & 0xFFFFu, port);
+                authorized = V.authorized(tgt, port, cred);
+            }
+        }
         const bool reach = out_ok & in_ok & (bool)((t1.y >> port) & 1u);                        // not BLOCKED_BY_*_FIREWALL, not SCANNING_UNOPEN_PORT
-        const bool authorized = (auth >> (cred & 63u)) & 1ull;                                  // actions.py:608-621, precomputed per (node, port)
         const bool c_proceed = reach & running & authorized;
         const double c_fail_raw = (reach & !running) ? 0.0 : -10.0;
 
         // ---- exploit checks: MACHINE_NOT_RUNNING 0 > SUPSPICIOUSNESS -5 > LOCAL_EXPLOIT_FAILED -20 / FAILED_REMOTE_EXPLOIT -50 > REPEAT -1 ----
         const uint32_t vk = d1.z & 0xFFu, level = (d1.z >> 8) & 0xFFu;
-        const bool present = vk != 0xFFu;
+        const bool present = (vk != 0xFFu) & (bool)((own_present >> (col & 63u)) & 1ull);       // (random events: the key may have been patched away)
         const bool pre_ok = ((d1.y >> 16) >> tags) & 1u;                                        // precondition on (static props, tags)
         const bool esc = !k2 & (vk == MCBS_OUT_PRIVILEGE_ESCALATION);
         const bool repeat_esc = esc & (bool)((tags >> level) & 1u);                             // tag already on the node
@@ -379,6 +394,8 @@ __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, const Ste
     const uint32_t ec = active ? e : 0u;                // clamp so inactive lanes read valid memory and take no branch
     constexpr bool has_def = DEFK == MCBS_DEFENDER_SCAN_AND_REIMAGE;   // in-env defender, resolved at launch
     constexpr bool learned = DEFK == MCBS_DEFENDER_EXTERNAL;           // firewall rules are per-env state (learned defender)
+    constexpr bool ere = DEFK == MCBS_DEFENDER_RANDOM_EVENTS;          // ExternalRandomEvents: per-env vulnerability / service / firewall state
+    constexpr bool def_avail = has_def || ere;                         // a defender agent exists: availability goals and the SLA constraint apply
 
     // ---------------- level 1: loads whose addresses depend on the env index only ----------------
     uint8_t* body = S.body + (size_t)ec * S.body_stride;
@@ -419,7 +436,7 @@ __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, const Ste
     double pending = 0.0;
     if (PHASE != 1) {
         h1 = S.h1[ec];
-        if (has_def && C.rng_kind == MCBS_RNG_PHILOX) episode = S.episode[ec];
+        if (def_avail && C.rng_kind == MCBS_RNG_PHILOX) episode = S.episode[ec];
     }
     if (PHASE == 2) pending = S.pending[ec];
 
@@ -448,6 +465,7 @@ __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, const Ste
     for (int k = 0; k < M_COUNT; ++k)
 #pragma unroll
         for (int w = 0; w < WT; ++w) ln.m[k][w] = m0[k][w];
+    ln.ere_blob = T.base;
     if (!PK && S.wide) {                                // this lane's LDS column for the wide cached-triple set, behind the hot image
         ln.wide_lds = reinterpret_cast<uint64_t*>(topo_lds + (TOPO_LDS ? C.hot_bytes / 16u : 0u)) + threadIdx.x;
         ln.wide_stride = blockDim.x;
@@ -494,7 +512,7 @@ __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, const Ste
         ln.props = pt & ROW_PROPS_MASK; ln.tags = (uint32_t)(pt >> 60);
         ln.ever = r0.z; ln.since = r0.w;
         STAMP(3);  // row landed
-        ln.template act<!PK>(X, skip ? -1.0 : 0.0, kind, src, tgt, X ? (k0 ? a2 : (k1 ? cL + a3 : 0u)) : 0u, (X & k2) ? a3 : 0u, triple);
+        ln.template act<!PK, DEFK>(X, skip ? -1.0 : 0.0, kind, src, tgt, X ? (k0 ? a2 : (k1 ? cL + a3 : 0u)) : 0u, (X & k2) ? a3 : 0u, triple);
         // unchanged rows are written back as they were
         if (PK) reinterpret_cast<uint32_t*>(body + S.off_rows)[tgt] = S.tiny_pack(ln.props, ln.tags, ln.ever, ln.since);
         else {
@@ -531,12 +549,20 @@ __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, const Ste
                 ln.dclk = (ln.dclk + 1u) & 0xFFFFu;
             }
         }
+        if (ere) {
+            if (live & !oob) {                           // on_attacker_step_taken, then ExternalRandomEvents.step (env.py:1156-1158)
+                const EreView V{body, C, T.base, S.N};
+                h1.y = V.availability();
+                uint32_t di = 0;
+                random_events_step(V, [&]() { return ln.draw(di++, step, episode, io); });
+            }
+        }
         {
             // goals (env.py:1080-1116) on the state AFTER the defender acted, availability from BEFORE its scan
             const bool attacker_goal = (C.has_attacker_goal != 0) & !(h1.x < C.goal_reward) & !(ln.owned < C.goal_own_atleast) &
                                        !((double)ln.owned / (double)S.N < C.goal_own_atleast_percent) &
-                                       !(has_def && h1.y >= C.goal_low_availability);
-            const bool sla_broken = has_def && h1.y < C.maintain_sla;
+                                       !(def_avail && h1.y >= C.goal_low_availability);
+            const bool sla_broken = def_avail && h1.y < C.maintain_sla;
             const bool evicted = (C.defender_goal_eviction != 0) & (ln.owned == 0);
             const bool win = attacker_goal | sla_broken;
             const bool play = live & !oob;

@@ -68,6 +68,12 @@ class ScanAndReimageCompromisedMachines(DefenderAgent):
         self.scan_frequency = scan_frequency
 
 
+class ExternalRandomEvents(DefenderAgent):
+    """_env/defender.py:58-148: every step, on every node, with probability 0.1 each: patch a vulnerability away, stop a service,
+    plant a library vulnerability, remove a firewall rule, add an ALLOW rule on a random common port.  No parameters; the draws
+    come from the batch's Philox stream (or a tape, for parity with the reference's global generators)."""
+
+
 class OutOfBoundIndexError(Exception):
     """cyberbattle_env.py:135-136 (swallowed inside step, kept for API symmetry)"""
 
@@ -75,13 +81,17 @@ class OutOfBoundIndexError(Exception):
 def spec_from_kwargs(n_envs: int, maximum_total_credentials: int, maximum_node_count: int,
                      maximum_discoverable_credentials_per_action: int, defender_agent, attacker_goal, defender_goal,
                      defender_constraint, winning_reward: float, losing_reward: float, **extra) -> EnvSpec:
-    if defender_agent is not None and not isinstance(defender_agent, ScanAndReimageCompromisedMachines):
+    if defender_agent is not None and not isinstance(defender_agent, (ScanAndReimageCompromisedMachines, ExternalRandomEvents)):
         raise NotImplementedError(
             f"in-env defender {type(defender_agent).__name__} is not implemented on the device "
-            "(supported: ScanAndReimageCompromisedMachines; ExternalRandomEvents is a next-tier row, DESIGN.md section 9)")
+            "(supported: ScanAndReimageCompromisedMachines, ExternalRandomEvents)")
     goal = None if attacker_goal is None else dict(attacker_goal._asdict())
-    d = None if defender_agent is None else ("scan_and_reimage", defender_agent.probability, defender_agent.scan_capacity,
-                                             defender_agent.scan_frequency)
+    if defender_agent is None:
+        d = None
+    elif isinstance(defender_agent, ExternalRandomEvents):
+        d = ("random_events",)
+    else:
+        d = ("scan_and_reimage", defender_agent.probability, defender_agent.scan_capacity, defender_agent.scan_frequency)
     return EnvSpec(n_envs=n_envs, maximum_total_credentials=maximum_total_credentials, maximum_node_count=maximum_node_count,
                    maximum_discoverable_credentials_per_action=maximum_discoverable_credentials_per_action,
                    attacker_goal=goal, defender_goal_eviction=bool(defender_goal.eviction),

@@ -24,7 +24,8 @@ def _env_for(name, sj, **kw):
     common = dict(maximum_node_count=sj["maximum_node_count"], maximum_total_credentials=sj["maximum_total_credentials"],
                   maximum_discoverable_credentials_per_action=sj["maximum_discoverable_credentials_per_action"],
                   attacker_goal=ce.AttackerGoal(**g), defender_constraint=ce.DefenderConstraint(maintain_sla=sj["maintain_sla"]),
-                  defender_agent=None if d is None else ce.ScanAndReimageCompromisedMachines(d[1], d[2], d[3]),
+                  defender_agent=None if d is None else (ce.ExternalRandomEvents() if d[0] == "random_events" else
+                                                         ce.ScanAndReimageCompromisedMachines(d[1], d[2], d[3])),
                   winning_reward=sj["winning_reward"], losing_reward=sj["losing_reward"], throws_on_invalid_actions=False,
                   draw_tape=d is not None)
     common.update(kw)
@@ -89,6 +90,23 @@ def test_gym_facade_reproduces_reference_episode_from_seeds(name):
     env.close()
 
 
+def test_gym_facade_accepts_external_random_events():
+    """CyberBattleToyCtf(defender_agent=ExternalRandomEvents()) runs on the device; availability drops as services stop."""
+    from marlon_amd import cyberbattle_env as ce
+    env = ce.CyberBattleToyCtf(attacker_goal=ce.AttackerGoal(own_atleast_percent=1.0), defender_agent=ce.ExternalRandomEvents(),
+                               defender_constraint=ce.DefenderConstraint(maintain_sla=0.0), maximum_node_count=12,
+                               maximum_total_credentials=10, throws_on_invalid_actions=False, seed=5)
+    env.reset(seed=1)
+    lowest = 1.0
+    for _ in range(150):
+        obs, reward, done, truncated, info = env.step(env.sample_valid_action())
+        lowest = min(lowest, info["network_availability"])
+        if done:
+            env.reset()
+    assert lowest < 1.0
+    env.close()
+
+
 def test_gym_facade_errors_and_helpers():
     from marlon_amd import cyberbattle_env as ce
     with pytest.raises(ValueError, match=r"Network node count \(12\) exceeds the specified limit of 10"):
@@ -137,7 +155,8 @@ def test_attacker_vec_env_matches_marlon_wrappers(name):
     d = sj["defender"]
     env = AttackerVecEnv(topo, 1, maximum_node_count=sj["maximum_node_count"], maximum_total_credentials=sj["maximum_total_credentials"],
                          attacker_goal=ce.AttackerGoal(**sj["attacker_goal"]), defender_constraint=ce.DefenderConstraint(sj["maintain_sla"]),
-                         defender_agent=None if d is None else ce.ScanAndReimageCompromisedMachines(d[1], d[2], d[3]),
+                         defender_agent=None if d is None else (ce.ExternalRandomEvents() if d[0] == "random_events" else
+                                                         ce.ScanAndReimageCompromisedMachines(d[1], d[2], d[3])),
                          max_timesteps=sj["max_timesteps"], discrete=sj["discrete"], rng_kind=RNG_TAPE)
     _check_flat(env.observation, z, "first_", None, name + " reset")
     resets = 0

@@ -80,6 +80,9 @@ CASES = {
     "random24_defender": ("random24_defender_s51", dict(), 1024, 200),
     "ad6_wide_cache": ("ad6_mix_s70", dict(), 512, 200),          # 821 cacheable credentials: the set lives in memory / LDS
     "random_s5_defender": ("random_s5_defender_s67", dict(), 512, 150),
+    # ExternalRandomEvents with Philox draws: per-env vulnerability keys, service bits and firewall lists diverge between envs
+    "toyctf_randomevents": ("toyctf_randomevents_s81", dict(), 1024, 200),
+    "sink_randomevents": ("sink_randomevents_s83", dict(), 1024, 200),
 }
 
 
