@@ -54,6 +54,9 @@ struct mcbs_batch {
     StepCfg C{};
     StepCfg* C_dev = nullptr;       // device copy read by the step kernel through the scalar cache
     uint32_t* ere_lists_dev = nullptr;
+    // developer switches, read ONCE at batch creation (getenv on every launch costs more than the launch itself)
+    bool no_lds_topo = false, no_fused_masks = false, slow_masks = false;
+    uint32_t step_block_override = 0;
     uint8_t* arena = nullptr;       // every per-env column + bodies + init body, one allocation
     size_t arena_bytes = 0;
     ObsDigest* digest = nullptr;
@@ -249,6 +252,9 @@ extern "C" int mcbs_batch_create(const mcbs_topology* topo, const mcbs_batch_cfg
     if (!b) return fail(MCBS_ENOMEM, "out of memory");
     b->topo = topo;
     b->cfg = *cfg;
+    b->no_lds_topo = getenv("MCBS_NO_LDS_TOPO") != nullptr; b->no_fused_masks = getenv("MCBS_NO_FUSED_MASKS") != nullptr;
+    b->slow_masks = getenv("MCBS_SLOW_MASKS") != nullptr;
+    if (const char* ov = getenv("MCBS_STEP_BLOCK")) b->step_block_override = (uint32_t)atoi(ov);   // experiments only (64, 128 or 256)
     const uint32_t E = cfg->n_envs, N = h->n_nodes;
     DevState& S = b->S;
     S.E = E; S.N = N; S.NW = (N + 63) / 64;
@@ -469,13 +475,13 @@ static int timing_end(mcbs_batch* b, hipStream_t st, size_t slot) {
 template <int PHASE, int WT, int DEF>
 static void launch_step_v(mcbs_batch* b, const StepIO& io, hipStream_t st) {
     const uint32_t E = b->S.E, lds = b->C.hot_bytes;
-    if (lds <= 60000u && !getenv("MCBS_NO_LDS_TOPO")) {
+    if (lds <= 60000u && !b->no_lds_topo) {
         // workgroup size: as large as still leaves one workgroup per CU (256) — every workgroup stages its own copy of the hot
         // image, so at 65 536 envs 64-thread workgroups re-read it 4x as often as 256-thread ones (5.79 vs 5.48 us/step), while
         // 512 threads would leave half of the CUs idle (6.29 us)
         uint32_t block = lds <= 8192u ? 64u : 256u;
         while (block < 256u && E / (block * 2u) >= 256u) block *= 2u;
-        if (const char* ov = getenv("MCBS_STEP_BLOCK")) block = (uint32_t)atoi(ov);   // experiments only (64, 128 or 256)
+        if (b->step_block_override) block = b->step_block_override;
         hipLaunchKernelGGL((step_kernel<PHASE, WT, true, DEF>), dim3((E + block - 1) / block), dim3(block), lds + (b->S.wide ? block * b->S.TW * 8u : 0u), st,
                            b->S, b->T, b->C_dev, io);
     } else {
@@ -527,7 +533,7 @@ static int launch_obs(mcbs_batch* b, const mcbs_obs_buffers* o, hipStream_t st, 
     O.Nmax = b->cfg.maximum_node_count; O.Cmax = b->cfg.maximum_total_credentials; O.K = b->cfg.maximum_discoverable_credentials_per_action;
     // small action spaces: the per-env wavefront also writes mask_remote / mask_connect (mcbs_obs.hip)
     const size_t rows = (size_t)O.Nmax * O.Nmax, RL = (size_t)b->C.P * O.Cmax;
-    const bool small = rows <= 256 && !getenv("MCBS_NO_FUSED_MASKS");
+    const bool small = rows <= 256 && !b->no_fused_masks;
     O.fuse_remote = small && o->mask_remote && (rows * b->C.R) % 4 == 0 && reinterpret_cast<uintptr_t>(o->mask_remote) % 4 == 0;
     const size_t ML = (size_t)O.Nmax * b->C.L, MR = rows * b->C.R, M = rows * RL;
     const bool dwords_ok = small && RL >= 4 && RL + 4 <= 1040 && M % 4 == 0;     // the row pattern fits its kilobyte of LDS
@@ -560,7 +566,7 @@ static int launch_region(mcbs_batch* b, int8_t* dst, size_t env_stride, size_t r
     const dim3 grid(b->S.E, (unsigned)((chunks + 255) / 256));
     if (grid.y > 65535u) return fail(MCBS_ELIMIT, "mask region too large for one launch");
     const uint32_t RL = REGION == 0 ? b->C.P * Cm : (REGION == 1 ? Nm * b->C.R : 0u), Cc = REGION == 0 ? Cm : RL;
-    if (W == 16 && REGION != 2 && RL >= 16u && len < (1ull << 31) && !getenv("MCBS_SLOW_MASKS")) {
+    if (W == 16 && REGION != 2 && RL >= 16u && len < (1ull << 31) && !b->slow_masks) {
         auto fd = [](uint32_t d) {   // n / d = (t + ((n - t) >> sh1)) >> sh2 with t = mulhi(n, mul)
             uint32_t l = 0;
             while ((1ull << l) < d) ++l;
