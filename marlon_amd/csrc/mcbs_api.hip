@@ -136,6 +136,26 @@ extern "C" int mcbs_topology_create(const void* blob, size_t nbytes, int32_t dev
     if ((rc = check_section(h, h->off_fw_list0, 2u * (size_t)h->n_fw_lists, "fw_list0"))) return rc;
     for (uint32_t n = 0; n < h->n_nodes; ++n)
         if ((ns[n].fw_lists & 0xFFFFu) >= h->n_fw_lists || (ns[n].fw_lists >> 16) >= h->n_fw_lists) return fail(MCBS_EINVAL, "node %u: firewall list id", n);
+    if (h->off_ere) {          // ExternalRandomEvents tables: every index a kernel will use as a bit position or an array subscript
+        if ((rc = check_section(h, h->off_ere, sizeof(mcbs_ere_tables), "ere"))) return rc;
+        const mcbs_ere_tables* et = reinterpret_cast<const mcbs_ere_tables*>(b + h->off_ere);
+        const uint32_t W = h->n_local + h->n_remote;
+        const size_t room = h->total_bytes - h->off_ere;
+        if (W > 64u || et->n_library > W || et->key_cap == 0 || et->key_cap > 255u ||
+            (size_t)et->off_own_keys + (size_t)et->key_cap * h->n_nodes > room || (size_t)et->off_own_cnt + h->n_nodes > room ||
+            (size_t)et->off_lib_sorted + et->n_library > room)
+            return fail(MCBS_EINVAL, "topology blob: random-events tables out of range");
+        const uint8_t* eb = reinterpret_cast<const uint8_t*>(et);
+        for (uint32_t n = 0; n < h->n_nodes; ++n) {
+            const uint32_t cnt = eb[et->off_own_cnt + n];
+            if (cnt + et->n_library > et->key_cap) return fail(MCBS_EINVAL, "node %u: vulnerability key list longer than its capacity", n);
+            for (uint32_t k = 0; k < cnt; ++k)
+                if (eb[et->off_own_keys + (size_t)n * et->key_cap + k] >= W) return fail(MCBS_EINVAL, "node %u: vulnerability key out of range", n);
+        }
+        for (uint32_t i = 0; i < et->n_library; ++i) if (eb[et->off_lib_sorted + i] >= W) return fail(MCBS_EINVAL, "library column out of range");
+        for (int i = 0; i < 7; ++i) if (et->sample_name[i] >= h->n_names) return fail(MCBS_EINVAL, "sample port name out of range");
+        if (W < 64u && (et->lib_cols >> W)) return fail(MCBS_EINVAL, "library column mask out of range");
+    }
     const uint8_t* io = b + h->off_init_order;
     if (h->n_init_owned > h->n_nodes) return fail(MCBS_EINVAL, "init order");
     for (uint32_t i = 0; i < h->n_init_owned; ++i) if (io[i] >= h->n_nodes) return fail(MCBS_EINVAL, "init order");

@@ -391,25 +391,26 @@ def flatten(environment) -> FlatTopology:
     # (numpy.setdiff1d returns sorted names), the name ids of the ports it may open
     col_of = {vid: k for k, vid in enumerate(local_ids)}
     col_of.update({vid: L + k for k, vid in enumerate(remote_ids)})
-    if L + R > 64:
-        raise ValueError("more than 64 vulnerability identifiers")
-    own_lists = [[col_of[vid] for vid in info.vulnerabilities] for _, info in nodes]
-    key_cap = max(1, max(len(k) for k in own_lists) + len(library))
-    own_keys = np.full((N, key_cap), 0xFF, np.uint8)
-    for i, ks in enumerate(own_lists):
-        own_keys[i, :len(ks)] = ks
-    ere = np.zeros(1, ERE_DT)
-    ere["n_library"], ere["key_cap"] = len(library), key_cap
-    ere["lib_cols"] = sum(1 << col_of[vid] for vid in library)
-    ere["sample_name"][0, :7] = [name_index[p] for p in SAMPLE_PORTS]
-    ere_base = ERE_DT.itemsize
-    ere_arrays = [("off_own_keys", own_keys.tobytes()), ("off_own_cnt", np.array([len(k) for k in own_lists], np.uint8).tobytes()),
-                  ("off_lib_sorted", np.array([col_of[vid] for vid in sorted(library)], np.uint8).tobytes())]
-    ere_body = bytearray()
-    for field, data in ere_arrays:                     # offsets relative to the start of the section
-        ere_body += b"\0" * ((-(ere_base + len(ere_body))) % 4)
-        ere[field] = ere_base + len(ere_body)
-        ere_body += data
+    ere_section = b""                                   # more than 64 identifiers: no tables, that defender is refused for this topology
+    if L + R <= 64:
+        own_lists = [[col_of[vid] for vid in info.vulnerabilities] for _, info in nodes]
+        key_cap = max(1, max(len(k) for k in own_lists) + len(library))
+        own_keys = np.full((N, key_cap), 0xFF, np.uint8)
+        for i, ks in enumerate(own_lists):
+            own_keys[i, :len(ks)] = ks
+        ere = np.zeros(1, ERE_DT)
+        ere["n_library"], ere["key_cap"] = len(library), key_cap
+        ere["lib_cols"] = sum(1 << col_of[vid] for vid in library)
+        ere["sample_name"][0, :7] = [name_index[p] for p in SAMPLE_PORTS]
+        ere_base = ERE_DT.itemsize
+        ere_arrays = [("off_own_keys", own_keys.tobytes()), ("off_own_cnt", np.array([len(k) for k in own_lists], np.uint8).tobytes()),
+                      ("off_lib_sorted", np.array([col_of[vid] for vid in sorted(library)], np.uint8).tobytes())]
+        ere_body = bytearray()
+        for field, data in ere_arrays:                     # offsets relative to the start of the section
+            ere_body += b"\0" * ((-(ere_base + len(ere_body))) % 4)
+            ere[field] = ere_base + len(ere_body)
+            ere_body += data
+        ere_section = ere.tobytes() + bytes(ere_body)
 
     sections = [
         ("node", node_tab.tobytes()), ("slot_of", slot_of.tobytes()), ("slot", slot_tab.tobytes()),
@@ -418,7 +419,7 @@ def flatten(environment) -> FlatTopology:
         ("code", bytes(code)), ("init_order", init_order.tobytes()),
         ("fw_rule", np.array(fw_rules, np.uint8).reshape(-1, 2).tobytes()), ("fw_range", np.array(fw_range, np.uint16).reshape(-1, 2).tobytes()),
         ("fw_list0", np.array(fw_list0, np.uint16).tobytes()),
-        ("ere", ere.tobytes() + bytes(ere_body)),
+        ("ere", ere_section),
     ]
     hdr = np.zeros(1, HEADER_DT)
     h = hdr[0]
@@ -427,7 +428,7 @@ def flatten(environment) -> FlatTopology:
     for name, data in sections:
         pad = (-(base + len(body))) % 16
         body += b"\0" * pad
-        h["off_" + name] = base + len(body)
+        h["off_" + name] = base + len(body) if (data or name != "ere") else 0
         body += data
     body += b"\0" * ((-(base + len(body))) % 16)
     h["magic"], h["abi_version"], h["header_bytes"] = TOPO_MAGIC, ABI_VERSION, base
