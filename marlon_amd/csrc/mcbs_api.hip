@@ -565,7 +565,7 @@ static int launch_obs(mcbs_batch* b, const mcbs_obs_buffers* o, hipStream_t st, 
     O.fuse_discrete = dwords_ok && o->mask_discrete && ML % 4 == 0 && MR % 4 == 0 && b->C.L > 0 && b->C.R > 0 &&
                       reinterpret_cast<uintptr_t>(o->mask_discrete) % 4 == 0;
     hipLaunchKernelGGL(obs_small_kernel, dim3((b->S.E + 3) / 4), dim3(256), 4u * obs_stage_bytes(b->S.N, b->topo->H()->n_triples), st,
-                       b->S, b->T, b->C, O, b->digest);
+                       b->S, b->T, b->C_dev, O, b->digest);
     int rc = launch_ok("obs_small");
     if (rc) return rc;
     mcbs_obs_buffers rest = *o;                // what the fused wavefront has not written
@@ -609,9 +609,9 @@ static int launch_region(mcbs_batch* b, int8_t* dst, size_t env_stride, size_t r
 #undef MCBS_LAUNCH_FAST
         return launch_ok("mask (fast)");
     }
-    if (W == 16) hipLaunchKernelGGL((mask_kernel<16, REGION>), grid, dim3(256), 0, st, b->S, b->T, b->C, b->digest, dst, env_stride, region_off, Nm, Cm, env_mask, masks_only ? 0u : 1u);
-    else if (W == 4) hipLaunchKernelGGL((mask_kernel<4, REGION>), grid, dim3(256), 0, st, b->S, b->T, b->C, b->digest, dst, env_stride, region_off, Nm, Cm, env_mask, masks_only ? 0u : 1u);
-    else hipLaunchKernelGGL((mask_kernel<1, REGION>), grid, dim3(256), 0, st, b->S, b->T, b->C, b->digest, dst, env_stride, region_off, Nm, Cm, env_mask, masks_only ? 0u : 1u);
+    if (W == 16) hipLaunchKernelGGL((mask_kernel<16, REGION>), grid, dim3(256), 0, st, b->S, b->T, b->C_dev, b->digest, dst, env_stride, region_off, Nm, Cm, env_mask, masks_only ? 0u : 1u);
+    else if (W == 4) hipLaunchKernelGGL((mask_kernel<4, REGION>), grid, dim3(256), 0, st, b->S, b->T, b->C_dev, b->digest, dst, env_stride, region_off, Nm, Cm, env_mask, masks_only ? 0u : 1u);
+    else hipLaunchKernelGGL((mask_kernel<1, REGION>), grid, dim3(256), 0, st, b->S, b->T, b->C_dev, b->digest, dst, env_stride, region_off, Nm, Cm, env_mask, masks_only ? 0u : 1u);
     return launch_ok("mask");
 }
 
@@ -667,7 +667,7 @@ extern "C" int mcbs_step_info(mcbs_batch* b, const mcbs_info_buffers* info, void
 
 extern "C" int mcbs_sample_actions(mcbs_batch* b, int32_t valid, uint64_t seed, uint64_t step, int32_t* actions_out, void* stream) {
     if (!b || !actions_out) return fail(MCBS_EINVAL, "null argument");
-    hipLaunchKernelGGL(sample_kernel, dim3((b->S.E + 127) / 128), dim3(128), 0, (hipStream_t)stream, b->S, b->T, b->C, (int)valid, seed, step,
+    hipLaunchKernelGGL(sample_kernel, dim3((b->S.E + 127) / 128), dim3(128), 0, (hipStream_t)stream, b->S, b->T, b->C_dev, (int)valid, seed, step,
                        b->cfg.maximum_node_count, b->cfg.maximum_total_credentials, actions_out);
     return launch_ok("sample");
 }
@@ -675,7 +675,7 @@ extern "C" int mcbs_sample_actions(mcbs_batch* b, int32_t valid, uint64_t seed, 
 extern "C" int mcbs_decode_attacker_actions(mcbs_batch* b, const int64_t* multidiscrete, const int64_t* discrete,
                                             int32_t* actions_out, uint8_t* invalid_out, void* stream) {
     if (!b || !actions_out || !invalid_out || (!multidiscrete == !discrete)) return fail(MCBS_EINVAL, "need exactly one action encoding and both outputs");
-    hipLaunchKernelGGL(decode_kernel, dim3((b->S.E + 255) / 256), dim3(256), 0, (hipStream_t)stream, b->S, b->C,
+    hipLaunchKernelGGL(decode_kernel, dim3((b->S.E + 255) / 256), dim3(256), 0, (hipStream_t)stream, b->S, b->C_dev,
                        b->cfg.maximum_node_count, b->cfg.maximum_total_credentials, multidiscrete, discrete, actions_out, invalid_out);
     return launch_ok("decode");
 }

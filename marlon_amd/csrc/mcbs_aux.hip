@@ -43,8 +43,9 @@ __global__ __launch_bounds__(256) void info_kernel(DevState S, StepIO io) {
 // uniform among the nodes with privilege >= LocalUser, target uniform among the discovered nodes, vulnerability /
 // port / credential uniform, whole action re-drawn until the action mask allows it.  (The reference draws from
 // PCG64 streams; only the distribution is reproduced here — this is harness, not part of the step's parity.)
-__global__ __launch_bounds__(128) void sample_kernel(DevState S, Topo T, StepCfg C, int valid, uint64_t seed, uint64_t step,
+__global__ __launch_bounds__(128) void sample_kernel(DevState S, Topo T, const StepCfg* __restrict__ Cp, int valid, uint64_t seed, uint64_t step,
                                                     uint32_t Nmax, uint32_t Cmax, int32_t* out) {
+    const StepCfg& C = *Cp;   // device copy: by value it would push the arguments past 256 bytes (profiles/round1_notes.md)
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= S.E) return;
     const uint64_t gid = C.env_id_base + e;
@@ -101,8 +102,9 @@ __global__ __launch_bounds__(128) void sample_kernel(DevState S, Topo T, StepCfg
 
 // AttackerEnvWrapper.step's decode + out-of-range interception (attack_wrapper.py:255-308, :236-253) and
 // MaskedDiscreteAttackerWrapper._decode (action_masking.py:112-142), one lane per env.
-__global__ __launch_bounds__(256) void decode_kernel(DevState S, StepCfg C, uint32_t Nmax, uint32_t Cmax, const int64_t* md,
+__global__ __launch_bounds__(256) void decode_kernel(DevState S, const StepCfg* __restrict__ Cp, uint32_t Nmax, uint32_t Cmax, const int64_t* md,
                                                     const int64_t* discrete, int32_t* out, uint8_t* invalid) {
+    const StepCfg& C = *Cp;   // device copy: by value it would push the arguments past 256 bytes (profiles/round1_notes.md)
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= S.E) return;
     const int64_t nd = (int64_t)(S.h0[e].z & 0xFFFFu);

@@ -61,7 +61,8 @@ __device__ __forceinline__ ObsStage obs_stage_at(uint8_t* base, uint32_t n_nodes
 // everything about discovered node i and lane r everything about cached credential r in one burst (three dependent levels:
 // header; the two lists; rows / static tables), parks it in LDS by external index, and the rest of the kernel only computes
 // from LDS and streams stores.
-__global__ __launch_bounds__(256) void obs_small_kernel(DevState S, Topo T, StepCfg C, ObsIO O, ObsDigest* digest) {
+__global__ __launch_bounds__(256) void obs_small_kernel(DevState S, Topo T, const StepCfg* __restrict__ Cp, ObsIO O, ObsDigest* digest) {
+    const StepCfg& C = *Cp;   // device copy: by value it would push the arguments past 256 bytes (profiles/round1_notes.md)
     extern __shared__ uint4 obs_lds[];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;   // wave index as a scalar
     const uint32_t e = blockIdx.x * 4u + wave;
@@ -302,9 +303,10 @@ __global__ __launch_bounds__(256) void obs_small_kernel(DevState S, Topo T, Step
 
 // REGION 0: connect [N,N,P,C]   1: remote [N,N,R]   2: local [N,L]
 template <int W, int REGION>
-__global__ __launch_bounds__(256) void mask_kernel(DevState S, Topo T, StepCfg C, const ObsDigest* digest, int8_t* dst,
+__global__ __launch_bounds__(256) void mask_kernel(DevState S, Topo T, const StepCfg* __restrict__ Cp, const ObsDigest* digest, int8_t* dst,
                                                    size_t env_stride, size_t region_off, uint32_t Nm, uint32_t Cm, const uint8_t* env_mask,
                                                    uint32_t skip_flagged) {
+    const StepCfg& C = *Cp;
     const uint32_t e = blockIdx.x;
     if (env_mask && !env_mask[e]) return;      // uniform per workgroup
     if (skip_flagged && (S.h0[e].y & F_SKIP)) return;
@@ -429,9 +431,9 @@ __global__ __launch_bounds__(256) void mask_fast_kernel(DevState S, const ObsDig
 }
 
 #define MCBS_INST(W) \
-    template __global__ void mask_kernel<W, 0>(DevState, Topo, StepCfg, const ObsDigest*, int8_t*, size_t, size_t, uint32_t, uint32_t, const uint8_t*, uint32_t); \
-    template __global__ void mask_kernel<W, 1>(DevState, Topo, StepCfg, const ObsDigest*, int8_t*, size_t, size_t, uint32_t, uint32_t, const uint8_t*, uint32_t); \
-    template __global__ void mask_kernel<W, 2>(DevState, Topo, StepCfg, const ObsDigest*, int8_t*, size_t, size_t, uint32_t, uint32_t, const uint8_t*, uint32_t);
+    template __global__ void mask_kernel<W, 0>(DevState, Topo, const StepCfg*, const ObsDigest*, int8_t*, size_t, size_t, uint32_t, uint32_t, const uint8_t*, uint32_t); \
+    template __global__ void mask_kernel<W, 1>(DevState, Topo, const StepCfg*, const ObsDigest*, int8_t*, size_t, size_t, uint32_t, uint32_t, const uint8_t*, uint32_t); \
+    template __global__ void mask_kernel<W, 2>(DevState, Topo, const StepCfg*, const ObsDigest*, int8_t*, size_t, size_t, uint32_t, uint32_t, const uint8_t*, uint32_t);
 MCBS_INST(16)
 MCBS_INST(4)
 MCBS_INST(1)
