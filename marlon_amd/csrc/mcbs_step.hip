@@ -444,7 +444,20 @@ __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, const Ste
     const uint8_t* tb = T.hot;
     if (TOPO_LDS) {                                     // cooperative copy of the hot topology image, 16 bytes per lane
         const uint4* src = reinterpret_cast<const uint4*>(T.hot);
-        for (uint32_t i = threadIdx.x; i < C.hot_bytes / 16u; i += blockDim.x) topo_lds[i] = src[i];
+        const uint32_t nvec = C.hot_bytes / 16u, bd = blockDim.x;
+        if (PK || nvec <= 2u * bd) {                    // small image (Chain-10: 1.1 passes): the plain loop is the fastest here; packed
+                                                        // batches (<= 16 nodes) never have a large one, and their kernel keeps exactly this code
+            for (uint32_t i = threadIdx.x; i < nvec; i += bd) topo_lds[i] = src[i];
+        } else {                                        // large image (Chain-100: 8 passes): four loads in flight per lane, not one —
+            for (uint32_t i = threadIdx.x; i < nvec; i += 4u * bd) {   // a plain loop waits for each pass before issuing the next
+                const uint32_t i1 = i + bd, i2 = i + 2u * bd, i3 = i + 3u * bd, last = nvec - 1u;
+                const uint4 v0 = src[i], v1 = src[i1 < nvec ? i1 : last], v2 = src[i2 < nvec ? i2 : last], v3 = src[i3 < nvec ? i3 : last];
+                topo_lds[i] = v0;
+                if (i1 < nvec) topo_lds[i1] = v1;
+                if (i2 < nvec) topo_lds[i2] = v2;
+                if (i3 < nvec) topo_lds[i3] = v3;
+            }
+        }
         __syncthreads();
         tb = reinterpret_cast<const uint8_t*>(topo_lds);
     }
