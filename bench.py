@@ -174,6 +174,21 @@ def main() -> int:
     kernel_us = region_us
     same = bool(torch.equal(rewards.double().sum(dim=0), reward_sum_timed))
 
+    # ---- extra, NOT the headline: the same K recorded steps through mcbs_step_many (one launch, no per-step launch cost) ----
+    eng.reset()
+    for t in range(W):
+        launch(t, t % K, st)
+    many_r = torch.empty((K, E), dtype=torch.float32, device=dev)
+    many_d = torch.empty((K, E), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    m0, m1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    m0.record()
+    eng.step_many(ring[W:W + K], many_r, many_d)
+    m1.record()
+    torch.cuda.synchronize()
+    many_us = m0.elapsed_time(m1) * 1e3 / K
+    many_same = bool(torch.equal(many_r.double().sum(dim=0), reward_sum_timed))
+
     # ---- optional logging collective (not on the data path): episode returns of every rank ----
     if world > 1:
         mine = reward_sum_timed.to(coll_dev)
@@ -214,6 +229,8 @@ def main() -> int:
                          "kernel_us_event_pair_per_launch": pair_us,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "bytes_per_env_step": B_STEP,
                          "replay_rewards_equal_timed_region": same},
+            # scripted-sequence entry point (no reference counterpart): K steps in ONE launch; reported beside, never as, `value`
+            "step_many": {"us_per_step": many_us, "env_steps_per_s_rank0": E / (many_us * 1e-6), "rewards_equal_timed_region": many_same},
         }
         if not args.no_cpu_baseline:
             n = min(args.cpu_envs, E)

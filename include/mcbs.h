@@ -295,6 +295,13 @@ int  mcbs_reset(mcbs_batch*, const uint8_t* env_mask, void* stream);
 int  mcbs_step(mcbs_batch*, const int32_t* actions, float* reward, uint8_t* terminated,
                const mcbs_info_buffers* info, void* stream);
 
+/* n_steps consecutive steps of every env in ONE launch, for action sequences that are known in advance (recorded traces,
+ * scripted plans, pre-sampled random agents: marlon.simulate's random-agent loops, marlon/simulate.py:14-35):
+ * actions [n_steps, E, 5], reward / terminated [n_steps, E].  Identical in effect to n_steps calls of mcbs_step without info
+ * buffers (auto-reset and truncation included); needs the Philox generator when a defender is configured.  The reference has
+ * no counterpart; what it saves is the cost between dependent launches. */
+int  mcbs_step_many(mcbs_batch*, const int32_t* actions, float* reward, uint8_t* terminated, uint32_t n_steps, void* stream);
+
 /* Same transition, but the observation is written exactly where the reference assembles it:
  * after the attacker's action and BEFORE the defender acts (env.py:1153 vs 1156-1158).
  * Three launches: attacker phase, observation, defender + goals. */

@@ -492,7 +492,7 @@ static int timing_end(mcbs_batch* b, hipStream_t st, size_t slot) {
 
 // Kernel variant: words per set kept in registers (1, 2 or 4), whether the topology tables fit the LDS budget, and
 // whether an in-env defender is configured (its code and loads are compiled out otherwise).
-template <int PHASE, int WT, int DEF>
+template <int PHASE, int WT, int DEF, bool MANY = false>
 static void launch_step_v(mcbs_batch* b, const StepIO& io, hipStream_t st) {
     const uint32_t E = b->S.E, lds = b->C.hot_bytes;
     if (lds <= 60000u && !b->no_lds_topo) {
@@ -502,28 +502,28 @@ static void launch_step_v(mcbs_batch* b, const StepIO& io, hipStream_t st) {
         uint32_t block = lds <= 8192u ? 64u : 256u;
         while (block < 256u && E / (block * 2u) >= 256u) block *= 2u;
         if (b->step_block_override) block = b->step_block_override;
-        hipLaunchKernelGGL((step_kernel<PHASE, WT, true, DEF>), dim3((E + block - 1) / block), dim3(block), lds + (b->S.wide ? block * b->S.TW * 8u : 0u), st,
+        hipLaunchKernelGGL((step_kernel<PHASE, WT, true, DEF, MANY>), dim3((E + block - 1) / block), dim3(block), lds + (b->S.wide ? block * b->S.TW * 8u : 0u), st,
                            b->S, b->T, b->C_dev, io);
     } else {
-        hipLaunchKernelGGL((step_kernel<PHASE, WT, false, DEF>), dim3((E + 127) / 128), dim3(128), b->S.wide ? 128u * b->S.TW * 8u : 0u, st,
+        hipLaunchKernelGGL((step_kernel<PHASE, WT, false, DEF, MANY>), dim3((E + 127) / 128), dim3(128), b->S.wide ? 128u * b->S.TW * 8u : 0u, st,
                            b->S, b->T, b->C_dev, io);
     }
 }
 
-template <int PHASE, int WT>
+template <int PHASE, int WT, bool MANY = false>
 static void launch_step_nw(mcbs_batch* b, const StepIO& io, hipStream_t st) {
-    if (b->cfg.defender_kind == MCBS_DEFENDER_SCAN_AND_REIMAGE) launch_step_v<PHASE, WT, MCBS_DEFENDER_SCAN_AND_REIMAGE>(b, io, st);
-    else if (b->cfg.defender_kind == MCBS_DEFENDER_RANDOM_EVENTS) launch_step_v<PHASE, WT, MCBS_DEFENDER_RANDOM_EVENTS>(b, io, st);
-    else if (b->cfg.defender_kind == MCBS_DEFENDER_EXTERNAL) launch_step_v<PHASE, WT, MCBS_DEFENDER_EXTERNAL>(b, io, st);
-    else launch_step_v<PHASE, WT, MCBS_DEFENDER_NONE>(b, io, st);
+    if (b->cfg.defender_kind == MCBS_DEFENDER_SCAN_AND_REIMAGE) launch_step_v<PHASE, WT, MCBS_DEFENDER_SCAN_AND_REIMAGE, MANY>(b, io, st);
+    else if (b->cfg.defender_kind == MCBS_DEFENDER_RANDOM_EVENTS) launch_step_v<PHASE, WT, MCBS_DEFENDER_RANDOM_EVENTS, MANY>(b, io, st);
+    else if (b->cfg.defender_kind == MCBS_DEFENDER_EXTERNAL) launch_step_v<PHASE, WT, MCBS_DEFENDER_EXTERNAL, MANY>(b, io, st);
+    else launch_step_v<PHASE, WT, MCBS_DEFENDER_NONE, MANY>(b, io, st);
 }
 
-template <int PHASE>
+template <int PHASE, bool MANY = false>
 static int launch_step(mcbs_batch* b, const StepIO& io, hipStream_t st, const char* what) {
-    if (b->S.packed) launch_step_nw<PHASE, 0>(b, io, st);       // WT 0: packed sets (one word of registers each)
-    else if (b->S.WT == 1) launch_step_nw<PHASE, 1>(b, io, st);
-    else if (b->S.WT == 2) launch_step_nw<PHASE, 2>(b, io, st);
-    else launch_step_nw<PHASE, 4>(b, io, st);
+    if (b->S.packed) launch_step_nw<PHASE, 0, MANY>(b, io, st);       // WT 0: packed sets (one word of registers each)
+    else if (b->S.WT == 1) launch_step_nw<PHASE, 1, MANY>(b, io, st);
+    else if (b->S.WT == 2) launch_step_nw<PHASE, 2, MANY>(b, io, st);
+    else launch_step_nw<PHASE, 4, MANY>(b, io, st);
     return launch_ok(what);
 }
 
@@ -538,6 +538,24 @@ extern "C" int mcbs_step(mcbs_batch* b, const int32_t* actions, float* reward, u
     int rc = timing_begin(b, st, &slot);
     if (rc) return rc;
     if ((rc = launch_step<0>(b, io, st, "step"))) return rc;
+    return timing_end(b, st, slot);
+}
+
+// n_steps consecutive steps in one launch: scripted / recorded / pre-sampled action sequences (replaying a trace, random-agent
+// baselines, evaluating fixed plans), where nothing has to be observed between steps.  Results are those of n_steps calls of
+// mcbs_step; what is saved is the per-launch cost between dependent launches (1.5 us of a 5.5 us step at 65 536 envs).
+extern "C" int mcbs_step_many(mcbs_batch* b, const int32_t* actions, float* reward, uint8_t* terminated, uint32_t n_steps, void* stream) {
+    if (!b || !actions || !reward || !terminated) return fail(MCBS_EINVAL, "null argument");
+    if (n_steps == 0) return MCBS_OK;
+    if (b->cfg.rng_kind == MCBS_RNG_TAPE && b->cfg.defender_kind != MCBS_DEFENDER_NONE)
+        return fail(MCBS_ESTATE, "mcbs_step_many needs the Philox generator: a draw tape holds one step's draws");
+    hipStream_t st = (hipStream_t)stream;
+    StepIO io = make_io(b, actions, reward, terminated, nullptr);
+    io.n_steps = n_steps;
+    size_t slot;
+    int rc = timing_begin(b, st, &slot);
+    if (rc) return rc;
+    if ((rc = launch_step<0, true>(b, io, st, "step (many)"))) return rc;
     return timing_end(b, st, slot);
 }
 

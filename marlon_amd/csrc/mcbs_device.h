@@ -164,6 +164,7 @@ struct StepIO {
     float* raw_reward;
     const double* tape;
     uint32_t tape_dps;
+    uint32_t n_steps;            // mcbs_step_many: steps in this launch (else unused)
 #ifdef MCBS_DIAG
     unsigned long long* stamps;  // diagnostic builds only: [waves][8] s_memtime stamps.  Kept out of the product build: the step
                                  // kernel's arguments must end below byte 256 (see mcbs_api.hip make_io)

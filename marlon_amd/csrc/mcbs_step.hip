@@ -370,7 +370,7 @@ struct Lane {
 // PHASE 2: defender, goals, outputs, auto-reset (after the observation kernels ran).
 // WT: words per set held in registers (1, 2 or 4; >= NW, SW, TW).  TOPO_LDS: topology tables staged in LDS.
 // DEFK: MCBS_DEFENDER_* (none / in-env ScanAndReimage / external learned defender).
-template <int PHASE, int WTP, bool TOPO_LDS, int DEFK>
+template <int PHASE, int WTP, bool TOPO_LDS, int DEFK, bool MANY = false>
 __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, const StepCfg* __restrict__ Cp, StepIO io) {
     constexpr bool PK = WTP == 0;           // packed batch: the eight sets are 16-bit fields of one uint4 per env
     constexpr int WT = PK ? 1 : WTP;
@@ -397,6 +397,19 @@ __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, const Ste
     constexpr bool ere = DEFK == MCBS_DEFENDER_RANDOM_EVENTS;          // ExternalRandomEvents: per-env vulnerability / service / firewall state
     constexpr bool def_avail = has_def || ere;                         // a defender agent exists: availability goals and the SLA constraint apply
 
+    // MANY: mcbs_step_many — n_steps consecutive steps of every env in ONE launch (action batches [n_steps, E, 5], outputs
+    // [n_steps, E]); each iteration is the whole step below against the state the previous one stored (a lane reads its own
+    // stores in program order; the reset copy is by lanes of the same wavefront).  Envs never interact, so no grid-wide
+    // synchronisation is involved; what goes away is the per-launch cost between dependent steps.
+    const uint32_t n_it = MANY ? io.n_steps : 1u;
+    const uint8_t* tb = TOPO_LDS ? reinterpret_cast<const uint8_t*>(topo_lds) : T.hot;
+    for (uint32_t it = 0; it < n_it; ++it) {
+    StepIO iok = io;
+    if (MANY) {
+        iok.actions = io.actions + (size_t)it * S.E * 5u;
+        iok.reward = io.reward + (size_t)it * S.E;
+        iok.terminated = io.terminated + (size_t)it * S.E;
+    }
     // ---------------- level 1: loads whose addresses depend on the env index only ----------------
     uint8_t* body = S.body + (size_t)ec * S.body_stride;
     const uint4 h0 = S.h0[ec];
@@ -404,7 +417,7 @@ __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, const Ste
     uint32_t a4 = 0;
     uint4 dhead = make_uint4(0, 0, 0, 0), chead0 = dhead, chead1 = dhead;
     if (PHASE != 2) {
-        const uint32_t* ap = reinterpret_cast<const uint32_t*>(io.actions) + (size_t)ec * 5;
+        const uint32_t* ap = reinterpret_cast<const uint32_t*>(iok.actions) + (size_t)ec * 5;
         a03 = make_uint4(ap[0], ap[1], ap[2], ap[3]);
         a4 = ap[4];
         dhead = *reinterpret_cast<const uint4*>(body + S.off_disc);
@@ -441,8 +454,8 @@ __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, const Ste
     if (PHASE == 2) pending = S.pending[ec];
 
     STAMP_NOWAIT(1);   // level-1 loads issued
-    const uint8_t* tb = T.hot;
-    if (TOPO_LDS) {                                     // cooperative copy of the hot topology image, 16 bytes per lane
+    if (!TOPO_LDS) tb = T.hot;
+    if (TOPO_LDS && it == 0u) {                         // cooperative copy of the hot topology image, 16 bytes per lane
         const uint4* src = reinterpret_cast<const uint4*>(T.hot);
         const uint32_t nvec = C.hot_bytes / 16u, bd = blockDim.x;
         if (PK || nvec <= 2u * bd) {                    // small image (Chain-10: 1.1 passes): the plain loop is the fastest here; packed
@@ -459,7 +472,6 @@ __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, const Ste
             }
         }
         __syncthreads();
-        tb = reinterpret_cast<const uint8_t*>(topo_lds);
     }
 
     STAMP(2);          // level-1 loads and the LDS copy have landed
@@ -586,13 +598,13 @@ __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, const Ste
         h1.x += reward;
         const bool trunc = live & !done & (C.max_episode_steps != 0) & (step >= C.max_episode_steps);
         {
-            io.reward[e] = (float)reward;
-            io.terminated[e] = live ? (done ? 1 : 0) : (uint8_t)((old_flags & F_DONE) ? 1 : 0);
-            if (io.truncated) io.truncated[e] = live ? (trunc ? 1 : 0) : (uint8_t)((old_flags & F_TRUNC) ? 1 : 0);
-            if (io.availability) io.availability[e] = h1.y;
-            if (io.step_count) io.step_count[e] = (int32_t)step;
-            if (io.oob) io.oob[e] = oob ? 1 : 0;
-            if (io.raw_reward) io.raw_reward[e] = live ? (float)ln.raw : 0.0f;
+            iok.reward[e] = (float)reward;
+            iok.terminated[e] = live ? (done ? 1 : 0) : (uint8_t)((old_flags & F_DONE) ? 1 : 0);
+            if (iok.truncated) iok.truncated[e] = live ? (trunc ? 1 : 0) : (uint8_t)((old_flags & F_TRUNC) ? 1 : 0);
+            if (iok.availability) iok.availability[e] = h1.y;
+            if (iok.step_count) iok.step_count[e] = (int32_t)step;
+            if (iok.oob) iok.oob[e] = oob ? 1 : 0;
+            if (iok.raw_reward) iok.raw_reward[e] = live ? (float)ln.raw : 0.0f;
             need_reset = (done | trunc) & (C.auto_reset != 0);
             flags |= (done ? F_DONE : 0u) | (trunc ? F_TRUNC : 0u);
             S.h0[e] = make_uint4(step, flags, ln.n_disc | (ln.n_creds << 16), ln.owned | (ln.dclk << 16));
@@ -643,6 +655,7 @@ __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, const Ste
             if (need_reset) reset_header(S, T, e, S.episode[e] + 1u);
         }
     }
+    }   // steps of this launch
 #ifdef MCBS_DIAG
     STAMP(6);
     if (io.stamps && (threadIdx.x & 63u) == 0) {

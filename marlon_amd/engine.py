@@ -22,7 +22,7 @@ LIB_PATH = os.path.join(_HERE, "libmcbs.so")
 EXPORTS = [
     "mcbs_last_error", "mcbs_abi_version", "mcbs_topology_create", "mcbs_topology_destroy", "mcbs_batch_create",
     "mcbs_batch_destroy", "mcbs_reset", "mcbs_step", "mcbs_step_observe", "mcbs_observe", "mcbs_observe_masked", "mcbs_action_mask", "mcbs_step_info",
-    "mcbs_sample_actions", "mcbs_decode_attacker_actions", "mcbs_defender_step", "mcbs_defender_observe", "mcbs_set_draw_tape", "mcbs_state_record_bytes", "mcbs_get_state", "mcbs_set_state",
+    "mcbs_step_many", "mcbs_sample_actions", "mcbs_decode_attacker_actions", "mcbs_defender_step", "mcbs_defender_observe", "mcbs_set_draw_tape", "mcbs_state_record_bytes", "mcbs_get_state", "mcbs_set_state",
     "mcbs_timing_enable", "mcbs_timing_read",
 ]
 
@@ -56,6 +56,7 @@ def load_library(path: Optional[str] = None):
     lib.mcbs_batch_destroy.argtypes = [C.c_void_p]
     lib.mcbs_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.mcbs_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(InfoBuffers), C.c_void_p]
+    lib.mcbs_step_many.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     lib.mcbs_step_observe.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(InfoBuffers),
                                       C.POINTER(ObsBuffers), C.c_void_p]
     lib.mcbs_observe.argtypes = [C.c_void_p, C.POINTER(ObsBuffers), C.c_void_p]
@@ -199,6 +200,21 @@ class BatchEngine:
         _check(self.lib, self.lib.mcbs_step(self._h, a.data_ptr(), self.reward.data_ptr(), self.terminated.data_ptr(),
                                             C.byref(self._info_struct) if with_info else None, self._stream()), "mcbs_step")
         return self.reward, self.terminated
+
+    def step_many(self, actions, rewards=None, terminated=None):
+        """K consecutive steps in one launch: actions [K, E, 5] int32 on the device (a recorded / scripted / pre-sampled sequence).
+        Returns (rewards [K, E] float32, terminated [K, E] uint8); same results as K calls of step()."""
+        t = self.torch
+        a = actions if (isinstance(actions, t.Tensor) and actions.dtype == t.int32 and actions.is_contiguous() and
+                        actions.device == self.device) else t.as_tensor(actions, dtype=t.int32, device=self.device).contiguous()
+        if a.dim() != 3 or a.shape[1] != self.E or a.shape[2] != 5:
+            raise ValueError(f"actions must be [K, {self.E}, 5]")
+        K = a.shape[0]
+        rewards = t.empty((K, self.E), dtype=t.float32, device=self.device) if rewards is None else rewards
+        terminated = t.empty((K, self.E), dtype=t.uint8, device=self.device) if terminated is None else terminated
+        _check(self.lib, self.lib.mcbs_step_many(self._h, a.data_ptr(), rewards.data_ptr(), terminated.data_ptr(), K, self._stream()),
+               "mcbs_step_many")
+        return rewards, terminated
 
     def step_observe(self, actions, obs: dict):
         a = self._actions(actions)

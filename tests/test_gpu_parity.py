@@ -222,6 +222,34 @@ def test_random_topologies_engine_vs_oracle(n_nodes, seed):
     eng.close()
 
 
+@pytest.mark.parametrize("trace,E", [("chain10_script", 4096), ("toyctf_defender_s11", 2048), ("chain100_defender_s31", 256),
+                                     ("toyctf_randomevents_s81", 512)])
+def test_step_many_equals_single_steps(trace, E):
+    """mcbs_step_many (K steps in one launch) == K calls of mcbs_step: rewards, terminations, final state; episodes end, auto-reset
+    and truncate inside the launch; packed and general layouts, in-env defenders with Philox draws."""
+    from marlon_amd._abi import RNG_PHILOX
+    _, sj = parity.load_trace(trace)
+    topo = parity.topology_for(trace)
+    spec = parity.spec_from_json(sj, n_envs=E, auto_reset=True, rng_kind=RNG_PHILOX, seed=31, max_episode_steps=60)
+    one = _engine().BatchEngine(topo, spec)
+    many = _engine().BatchEngine(topo, spec)
+    K = 150
+    t = one.torch
+    ring = t.empty((K, E, 5), dtype=t.int32, device=one.device)
+    r1 = t.empty((K, E), dtype=t.float32, device=one.device)
+    d1 = t.empty((K, E), dtype=t.uint8, device=one.device)
+    for k in range(K):
+        one.sample_actions(k % 3 != 0, seed=9, step=k, out=ring[k])
+        r, d = one.step(ring[k], with_info=False)
+        r1[k], d1[k] = r, d
+    r2, d2 = many.step_many(ring[:100])
+    r3, d3 = many.step_many(ring[100:])
+    assert t.equal(t.cat([r2, r3]), r1) and t.equal(t.cat([d2, d3]), d1)
+    _compare_states(one.get_state(), many.get_state(), trace)
+    one.close()
+    many.close()
+
+
 def test_full_size_properties_chain10_65536():
     """BASELINE.json headline size (65 536 envs, Chain-10): determinism, shard invariance (two half batches with
     env_id_base = the full batch), and state invariants that hold for any action sequence."""
