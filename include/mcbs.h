@@ -302,6 +302,13 @@ int  mcbs_step(mcbs_batch*, const int32_t* actions, float* reward, uint8_t* term
  * no counterpart; what it saves is the cost between dependent launches. */
 int  mcbs_step_many(mcbs_batch*, const int32_t* actions, float* reward, uint8_t* terminated, uint32_t n_steps, void* stream);
 
+/* Random agents on the device: n_steps steps in one launch, each env's action drawn inside the kernel from its own state
+ * (valid != 0: the distribution of CyberBattleEnv.sample_valid_action, env.py:959-1047; else uniform over the action space) with
+ * Philox keyed by (seed, global env id, first_step + k) — the action mcbs_sample_actions(valid, seed, first_step + k) would give.
+ * actions_out [n_steps, E, 5] may be NULL.  marlon.simulate's loop for random agents (marlon/simulate.py:14-35). */
+int  mcbs_rollout_random(mcbs_batch*, int32_t valid, uint64_t seed, uint64_t first_step, uint32_t n_steps,
+                         int32_t* actions_out, float* reward, uint8_t* terminated, void* stream);
+
 /* Same transition, but the observation is written exactly where the reference assembles it:
  * after the attacker's action and BEFORE the defender acts (env.py:1153 vs 1156-1158).
  * Three launches: attacker phase, observation, defender + goals. */

@@ -559,6 +559,29 @@ extern "C" int mcbs_step_many(mcbs_batch* b, const int32_t* actions, float* rewa
     return timing_end(b, st, slot);
 }
 
+// Random agents entirely on the device: every step's action is drawn from the env's own state inside the step kernel
+// (sample_action, the distribution of CyberBattleEnv.sample_valid_action or uniform over the action space), K steps per launch.
+// This is marlon.simulate's loop for random agents (marlon/simulate.py:14-35) without a launch per sample and per step.
+extern "C" int mcbs_rollout_random(mcbs_batch* b, int32_t valid, uint64_t seed, uint64_t first_step, uint32_t n_steps,
+                                   int32_t* actions_out, float* reward, uint8_t* terminated, void* stream) {
+    if (!b || !reward || !terminated) return fail(MCBS_EINVAL, "null argument");
+    if (n_steps == 0) return MCBS_OK;
+    if (b->cfg.rng_kind == MCBS_RNG_TAPE && b->cfg.defender_kind != MCBS_DEFENDER_NONE)
+        return fail(MCBS_ESTATE, "mcbs_rollout_random needs the Philox generator: a draw tape holds one step's draws");
+    hipStream_t st = (hipStream_t)stream;
+    struct { uint32_t mode, nmax, cmax, pad; uint64_t seed, step0; } roll = { valid ? 2u : 1u, b->cfg.maximum_node_count,
+                                                                             b->cfg.maximum_total_credentials, 0u, seed, first_step };
+    static_assert(offsetof(StepCfg, roll_step0) - offsetof(StepCfg, roll_mode) == 24, "roll block layout");
+    uint8_t* dst = reinterpret_cast<uint8_t*>(b->C_dev) + offsetof(StepCfg, roll_mode);
+    HIP_TRY(hipMemcpyAsync(dst, &roll, 32, hipMemcpyHostToDevice, st));
+    StepIO io = make_io(b, actions_out, reward, terminated, nullptr);
+    io.n_steps = n_steps;
+    int rc = launch_step<0, true>(b, io, st, "rollout");
+    const uint32_t off = 0;
+    HIP_TRY(hipMemcpyAsync(dst, &off, 4, hipMemcpyHostToDevice, st));     // later mcbs_step_many launches read their actions again
+    return rc;
+}
+
 static int launch_masks(mcbs_batch* b, const mcbs_obs_buffers* o, hipStream_t st, const uint8_t* env_mask, bool masks_only);
 
 static int launch_obs(mcbs_batch* b, const mcbs_obs_buffers* o, hipStream_t st, bool masks_only = false, const uint8_t* env_mask = nullptr) {

@@ -1,6 +1,7 @@
 // mcbs_aux.hip — reset, StepInfo export and the random-agent action samplers (gfx950).
 #pragma once
 #include "mcbs_device.h"
+#include "mcbs_sample.hip"
 
 namespace mcbs {
 
@@ -37,65 +38,14 @@ __global__ __launch_bounds__(256) void info_kernel(DevState S, StepIO io) {
     if (io.terminated) io.terminated[e] = (h0.y & F_DONE) ? 1 : 0;
 }
 
-// Random-agent harness.  valid == 0: every component uniform in its bound (cyberbattle_env.py action space,
-// :540-559), invalid and out-of-bound actions included.  valid != 0: the distribution of sample_valid_action
-// (:959-1047): kind uniform among {local, remote, connect} (connect only once a credential is cached), source
-// uniform among the nodes with privilege >= LocalUser, target uniform among the discovered nodes, vulnerability /
-// port / credential uniform, whole action re-drawn until the action mask allows it.  (The reference draws from
-// PCG64 streams; only the distribution is reproduced here — this is harness, not part of the step's parity.)
+// Random-agent harness: sample_action (mcbs_sample.hip), one lane per env.
 __global__ __launch_bounds__(128) void sample_kernel(DevState S, Topo T, const StepCfg* __restrict__ Cp, int valid, uint64_t seed, uint64_t step,
                                                     uint32_t Nmax, uint32_t Cmax, int32_t* out) {
     const StepCfg& C = *Cp;   // device copy: by value it would push the arguments past 256 bytes (profiles/round1_notes.md)
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= S.E) return;
-    const uint64_t gid = C.env_id_base + e;
-    uint32_t ctr = 0, buf[4], have = 0;
-    auto next_u32 = [&]() -> uint32_t {
-        if (!have) {
-            philox4x32_10((uint32_t)gid, (uint32_t)step, (uint32_t)(step >> 32), ctr++, (uint32_t)seed ^ 0x5A17ACEDu,
-                          (uint32_t)(seed >> 32) ^ (uint32_t)(gid >> 32), buf);
-            have = 4;
-        }
-        return buf[--have];
-    };
-    auto below = [&](uint32_t n) -> uint32_t { return n ? (uint32_t)(((uint64_t)next_u32() * n) >> 32) : 0u; };
-    int32_t a[5] = {0, 0, 0, 0, 0};
-    if (!valid) {
-        a[0] = (int32_t)below(3);
-        if (a[0] == 0) { a[1] = below(Nmax); a[2] = below(C.L); }
-        else if (a[0] == 1) { a[1] = below(Nmax); a[2] = below(Nmax); a[3] = below(C.R); }
-        else { a[1] = below(Nmax); a[2] = below(Nmax); a[3] = below(C.P); a[4] = below(Cmax); }
-    } else {
-        const uint4 h0 = S.h0[e];
-        const uint32_t n_disc = h0.z & 0xFFFFu, n_creds = h0.z >> 16, owned = h0.w & 0xFFFFu;
-        const uint8_t* dl = S.body + (size_t)e * S.body_stride + S.off_disc;
-        const mcbs_node_static* NS = reinterpret_cast<const mcbs_node_static*>(T.base + C.off_node);
-        auto owned_source = [&]() -> uint32_t {      // external index of the k-th owned node, k uniform
-            uint32_t k = below(owned);
-            for (uint32_t i = 0; i < n_disc; ++i) {
-                const uint32_t n = dl[i];
-                if (S.has(M_PLO, n, e) || S.has(M_PHI, n, e)) { if (k == 0) return i; k -= 1; }
-            }
-            return 0u;
-        };
-        for (int attempt = 0; attempt < 64; ++attempt) {
-            const uint32_t kind = below(n_creds ? 3u : 2u);
-            const uint32_t src = owned_source();
-            const uint32_t node = dl[src];
-            const bool installed = S.has(M_INST, node, e);
-            if (kind == 0) {
-                const uint32_t v = below(C.L);
-                a[0] = 0; a[1] = (int32_t)src; a[2] = (int32_t)v; a[3] = 0; a[4] = 0;
-                if (installed && ((local_mask_of(C, NS, S.body + (size_t)e * S.body_stride, node) >> v) & 1u)) break;
-            } else if (kind == 1) {
-                a[0] = 1; a[1] = (int32_t)src; a[2] = (int32_t)below(n_disc); a[3] = (int32_t)below(C.R); a[4] = 0;
-                if (installed) break;
-            } else {
-                a[0] = 2; a[1] = (int32_t)src; a[2] = (int32_t)below(n_disc); a[3] = (int32_t)below(C.P); a[4] = (int32_t)below(n_creds);
-                if (installed) break;
-            }
-        }
-    }
+    int32_t a[5];
+    sample_action(S, T, C, e, valid, seed, step, Nmax, Cmax, a);
     int32_t* o = out + (size_t)e * 5;
     o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = a[4];
 }

@@ -48,6 +48,7 @@
 #pragma once
 #include "mcbs_device.h"
 #include "mcbs_ere.hip"
+#include "mcbs_sample.hip"
 
 namespace mcbs {
 
@@ -406,7 +407,7 @@ __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, const Ste
     for (uint32_t it = 0; it < n_it; ++it) {
     StepIO iok = io;
     if (MANY) {
-        iok.actions = io.actions + (size_t)it * S.E * 5u;
+        iok.actions = io.actions ? io.actions + (size_t)it * S.E * 5u : nullptr;
         iok.reward = io.reward + (size_t)it * S.E;
         iok.terminated = io.terminated + (size_t)it * S.E;
     }
@@ -416,10 +417,21 @@ __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, const Ste
     uint4 a03 = make_uint4(0, 0, 0, 0);
     uint32_t a4 = 0;
     uint4 dhead = make_uint4(0, 0, 0, 0), chead0 = dhead, chead1 = dhead;
-    if (PHASE != 2) {
+    if (MANY && C.roll_mode) {                          // on-device random agent: this step's action comes from the env's own state
+        int32_t ra[5];
+        sample_action(S, T, C, ec, C.roll_mode == 2u, C.roll_seed, C.roll_step0 + it, C.roll_nmax, C.roll_cmax, ra);
+        a03 = make_uint4((uint32_t)ra[0], (uint32_t)ra[1], (uint32_t)ra[2], (uint32_t)ra[3]);
+        a4 = (uint32_t)ra[4];
+        if (io.actions && active) {
+            int32_t* o = const_cast<int32_t*>(iok.actions) + (size_t)e * 5;
+            o[0] = ra[0]; o[1] = ra[1]; o[2] = ra[2]; o[3] = ra[3]; o[4] = ra[4];
+        }
+    } else if (PHASE != 2) {
         const uint32_t* ap = reinterpret_cast<const uint32_t*>(iok.actions) + (size_t)ec * 5;
         a03 = make_uint4(ap[0], ap[1], ap[2], ap[3]);
         a4 = ap[4];
+    }
+    if (PHASE != 2) {
         dhead = *reinterpret_cast<const uint4*>(body + S.off_disc);
         chead0 = *reinterpret_cast<const uint4*>(body + S.off_cred);
         chead1 = *reinterpret_cast<const uint4*>(body + S.off_cred + 16);

@@ -22,7 +22,7 @@ LIB_PATH = os.path.join(_HERE, "libmcbs.so")
 EXPORTS = [
     "mcbs_last_error", "mcbs_abi_version", "mcbs_topology_create", "mcbs_topology_destroy", "mcbs_batch_create",
     "mcbs_batch_destroy", "mcbs_reset", "mcbs_step", "mcbs_step_observe", "mcbs_observe", "mcbs_observe_masked", "mcbs_action_mask", "mcbs_step_info",
-    "mcbs_step_many", "mcbs_sample_actions", "mcbs_decode_attacker_actions", "mcbs_defender_step", "mcbs_defender_observe", "mcbs_set_draw_tape", "mcbs_state_record_bytes", "mcbs_get_state", "mcbs_set_state",
+    "mcbs_step_many", "mcbs_rollout_random", "mcbs_sample_actions", "mcbs_decode_attacker_actions", "mcbs_defender_step", "mcbs_defender_observe", "mcbs_set_draw_tape", "mcbs_state_record_bytes", "mcbs_get_state", "mcbs_set_state",
     "mcbs_timing_enable", "mcbs_timing_read",
 ]
 
@@ -57,6 +57,7 @@ def load_library(path: Optional[str] = None):
     lib.mcbs_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.mcbs_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(InfoBuffers), C.c_void_p]
     lib.mcbs_step_many.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    lib.mcbs_rollout_random.argtypes = [C.c_void_p, C.c_int32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.mcbs_step_observe.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(InfoBuffers),
                                       C.POINTER(ObsBuffers), C.c_void_p]
     lib.mcbs_observe.argtypes = [C.c_void_p, C.POINTER(ObsBuffers), C.c_void_p]
@@ -215,6 +216,18 @@ class BatchEngine:
         _check(self.lib, self.lib.mcbs_step_many(self._h, a.data_ptr(), rewards.data_ptr(), terminated.data_ptr(), K, self._stream()),
                "mcbs_step_many")
         return rewards, terminated
+
+    def rollout_random(self, n_steps: int, valid: bool = True, seed: int = 0, first_step: int = 0, record_actions: bool = False):
+        """Random agents for n_steps steps in one launch (actions sampled inside the kernel, the distribution of sample_valid_action
+        or uniform).  Returns (rewards [K, E], terminated [K, E], actions [K, E, 5] or None)."""
+        t = self.torch
+        rewards = t.empty((n_steps, self.E), dtype=t.float32, device=self.device)
+        terminated = t.empty((n_steps, self.E), dtype=t.uint8, device=self.device)
+        actions = t.empty((n_steps, self.E, 5), dtype=t.int32, device=self.device) if record_actions else None
+        _check(self.lib, self.lib.mcbs_rollout_random(self._h, int(bool(valid)), int(seed) & (2 ** 64 - 1), int(first_step), int(n_steps),
+                                                      None if actions is None else actions.data_ptr(), rewards.data_ptr(),
+                                                      terminated.data_ptr(), self._stream()), "mcbs_rollout_random")
+        return rewards, terminated, actions
 
     def step_observe(self, actions, obs: dict):
         a = self._actions(actions)

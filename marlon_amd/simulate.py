@@ -50,3 +50,18 @@ def run_episodes(env: AttackerVecEnv, policy: Optional[Callable] = None, max_ste
         episodes += d
         returns += t.where(d, info["episode_return"], t.zeros_like(info["episode_return"]))
     return dict(rewards=rewards, dones=dones, episodes=episodes, returns=returns)
+
+
+def run_random_agents(engine, n_steps: int, valid: bool = True, seed: int = 0, chunk: int = 256) -> Dict[str, object]:
+    """Random attackers at the CyberBattleEnv level — the loop `env.step(env.sample_valid_action())` of CyberBattleSim's random
+    baseline and of marlon's RandomMarlonAgent — for every env of a BatchEngine, entirely on the device: `mcbs_rollout_random`
+    samples each action inside the step kernel, `chunk` steps per launch.  Returns device tensors `rewards` / `dones`
+    [n_steps, E] (auto-reset and truncation as configured in the batch's EnvSpec)."""
+    t = engine.torch
+    rewards = t.empty((n_steps, engine.E), dtype=t.float32, device=engine.device)
+    dones = t.empty((n_steps, engine.E), dtype=t.uint8, device=engine.device)
+    for s in range(0, n_steps, chunk):
+        k = min(chunk, n_steps - s)
+        r, d, _ = engine.rollout_random(k, valid=valid, seed=seed, first_step=s)
+        rewards[s:s + k], dones[s:s + k] = r, d
+    return dict(rewards=rewards, dones=dones)

@@ -250,6 +250,32 @@ def test_step_many_equals_single_steps(trace, E):
     many.close()
 
 
+@pytest.mark.parametrize("trace,valid", [("chain10_script", True), ("toyctf_defender_s11", True), ("chain10_script", False)])
+def test_rollout_random_equals_sample_then_step(trace, valid):
+    """mcbs_rollout_random (sampling inside the step kernel) == mcbs_sample_actions + mcbs_step, step by step: same actions, rewards,
+    terminations and final state."""
+    from marlon_amd._abi import RNG_PHILOX
+    _, sj = parity.load_trace(trace)
+    topo = parity.topology_for(trace)
+    E, K = 2048, 120
+    spec = parity.spec_from_json(sj, n_envs=E, auto_reset=True, rng_kind=RNG_PHILOX, seed=77, max_episode_steps=50)
+    one = _engine().BatchEngine(topo, spec)
+    fused = _engine().BatchEngine(topo, spec)
+    t = one.torch
+    acts, rews, dones = [], [], []
+    for k in range(K):
+        a = one.sample_actions(valid, seed=123, step=1000 + k)
+        r, d = one.step(a, with_info=False)
+        acts.append(a.clone()); rews.append(r.clone()); dones.append(d.clone())
+    r2, d2, a2 = fused.rollout_random(K, valid=valid, seed=123, first_step=1000, record_actions=True)
+    assert t.equal(a2, t.stack(acts)) and t.equal(r2, t.stack(rews)) and t.equal(d2, t.stack(dones))
+    _compare_states(one.get_state(), fused.get_state(), trace)
+    r3, d3 = fused.step_many(t.stack(acts)[:5])        # the sampling mode does not leak into later scripted launches
+    assert r3.shape == (5, E)
+    one.close()
+    fused.close()
+
+
 def test_full_size_properties_chain10_65536():
     """BASELINE.json headline size (65 536 envs, Chain-10): determinism, shard invariance (two half batches with
     env_id_base = the full batch), and state invariants that hold for any action sequence."""
