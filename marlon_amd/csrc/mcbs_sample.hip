@@ -39,23 +39,35 @@ __device__ inline void sample_action(const DevState& S, const Topo& T, const Ste
     const uint8_t* body = S.body + (size_t)e * S.body_stride;
     const uint8_t* dl = body + S.off_disc;
     const mcbs_node_static* NS = reinterpret_cast<const mcbs_node_static*>(T.base + C.off_node);
+    // one pass over the discovery order up front (independent loads), instead of set look-ups in memory inside every attempt:
+    // bit i of own_ext / inst_ext = the node at external index i has privilege >= LocalUser / has the agent installed
+    uint64_t plo[4] = {0, 0, 0, 0}, phi[4] = {0, 0, 0, 0}, inst[4] = {0, 0, 0, 0};
+    for (uint32_t w = 0; w < S.NW && w < 4u; ++w) { plo[w] = S.get(M_PLO, w, e); phi[w] = S.get(M_PHI, w, e); inst[w] = S.get(M_INST, w, e); }
+    uint64_t own_ext[4] = {0, 0, 0, 0}, inst_ext[4] = {0, 0, 0, 0};
+    for (uint32_t i = 0; i < n_disc; ++i) {
+        const uint32_t n = dl[i], w = (n >> 6) & 3u, b = n & 63u;
+        own_ext[(i >> 6) & 3u] |= (((plo[w] | phi[w]) >> b) & 1ull) << (i & 63u);
+        inst_ext[(i >> 6) & 3u] |= ((inst[w] >> b) & 1ull) << (i & 63u);
+    }
     auto owned_source = [&]() -> uint32_t {      // external index of the k-th owned node, k uniform
         uint32_t k = below(owned);
-        for (uint32_t i = 0; i < n_disc; ++i) {
-            const uint32_t n = dl[i];
-            if (S.has(M_PLO, n, e) || S.has(M_PHI, n, e)) { if (k == 0) return i; k -= 1; }
+        for (uint32_t c = 0; c < 4u; ++c) {
+            uint64_t m = own_ext[c];
+            const uint32_t pc = (uint32_t)__popcll(m);
+            if (k >= pc) { k -= pc; continue; }
+            while (k) { m &= m - 1ull; k -= 1u; }
+            return c * 64u + (uint32_t)__builtin_ctzll(m);
         }
         return 0u;
     };
     for (int attempt = 0; attempt < 64; ++attempt) {
         const uint32_t kind = below(n_creds ? 3u : 2u);
         const uint32_t src = owned_source();
-        const uint32_t node = dl[src];
-        const bool installed = S.has(M_INST, node, e);
+        const bool installed = (inst_ext[(src >> 6) & 3u] >> (src & 63u)) & 1ull;
         if (kind == 0) {
             const uint32_t v = below(C.L);
             a[0] = 0; a[1] = (int32_t)src; a[2] = (int32_t)v; a[3] = 0; a[4] = 0;
-            if (installed && ((local_mask_of(C, NS, body, node) >> v) & 1u)) break;
+            if (installed && ((local_mask_of(C, NS, body, dl[src]) >> v) & 1u)) break;
         } else if (kind == 1) {
             a[0] = 1; a[1] = (int32_t)src; a[2] = (int32_t)below(n_disc); a[3] = (int32_t)below(C.R); a[4] = 0;
             if (installed) break;
