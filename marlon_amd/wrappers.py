@@ -96,7 +96,7 @@ class AttackerVecEnv:
 
     def action_masks(self):
         """[n_envs, N*N*P*C + N*L + N*N*R] bool, MaskedDiscreteAttackerWrapper order (connect, local, remote)."""
-        return self._obs["mask_discrete"] != 0
+        return self._obs["mask_discrete"].view(self.torch.bool)      # the int8 mask holds 0 / 1 only: a bool view, no second gigabyte
 
     # -- VecEnv surface --
     def reset(self):
@@ -131,9 +131,10 @@ class AttackerVecEnv:
         info = {"invalid_action": invalid, "cyber_step_executed": ~invalid,
                 "network_availability": self.engine.info["network_availability"], "step_count": self.engine.info["step_count"],
                 "episode_return": self.episode_returns.clone(), "episode_length": self.timesteps.clone()}
-        if self.auto_reset and bool(dones.any()):
-            for k in self._obs:
-                self._terminal[k].copy_(self._obs[k])
+        ended = dones.nonzero().squeeze(1) if self.auto_reset else None        # (one host sync per step, like dones.any() before)
+        if ended is not None and ended.numel():
+            for k in self._obs:                       # terminal observation of the envs that ended only, not the whole batch
+                self._terminal[k].index_copy_(0, ended, self._obs[k].index_select(0, ended))
             mask = dones.to(t.uint8)
             self.engine.reset(mask)
             self.engine.observe(self._obs, env_mask=mask)   # reset observation for the envs that ended; the others keep theirs

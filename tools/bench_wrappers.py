@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Wrapper tier: one AttackerVecEnv.step (+ action_masks) per call — marlon's AttackerEnvWrapper / MaskedDiscreteAttackerWrapper
+semantics for a whole batch — with a trivial random masked policy, Chain-10 and ToyCtf."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from marlon_amd.wrappers import AttackerVecEnv  # noqa: E402
+from marlon_amd.samples import chainpattern, toy_ctf  # noqa: E402
+
+for name, env, E, kw in (("chain10", chainpattern.new_environment(10), 65536, dict(maximum_node_count=12, maximum_total_credentials=12)),
+                         ("toyctf", toy_ctf.new_environment(), 16384, dict(maximum_node_count=12, maximum_total_credentials=10))):
+    for discrete in (False, True):
+        venv = AttackerVecEnv(env, E, discrete=discrete, **kw)
+        venv.reset()
+        g = torch.Generator(device=venv.engine.device)
+        g.manual_seed(0)
+
+        def act():
+            if discrete:
+                m = venv.action_masks()
+                return torch.where(m, torch.rand(m.shape, generator=g, device=m.device), torch.full((1,), -1.0, device=m.device)).argmax(dim=1)
+            nvec = torch.as_tensor(venv.nvec, device=venv.engine.device)
+            return (torch.rand((E, len(nvec)), generator=g, device=nvec.device) * nvec).long()
+        for _ in range(5):
+            venv.step(act())
+        torch.cuda.synchronize()
+        K = 30
+        acts = [act() for _ in range(K)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for a in acts:
+            venv.step(a)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / K
+        t0 = time.perf_counter()
+        for _ in range(K):
+            venv.action_masks() if discrete else None
+        torch.cuda.synchronize()
+        dm = (time.perf_counter() - t0) / K
+        print(json.dumps(dict(topology=name, envs=E, discrete=discrete, step_us=dt * 1e6, action_masks_us=dm * 1e6,
+                              M_env_steps_per_s=E / dt / 1e6)))
+        venv.close()
