@@ -225,7 +225,7 @@ def main() -> int:
                        "episodes_ended_in_timed_region_rank0": n_done},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "mcbs::step_kernel<0, 0, true, 0>", "kernel_us": kernel_us, "launches_timed": K,
+                         "kernel": "mcbs::step_kernel<0, 0, true, 0, false>", "kernel_us": kernel_us, "launches_timed": K,
                          "kernel_us_event_pair_per_launch": pair_us,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "bytes_per_env_step": B_STEP,
                          "replay_rewards_equal_timed_region": same},
