@@ -55,7 +55,7 @@ struct mcbs_batch {
     StepCfg* C_dev = nullptr;       // device copy read by the step kernel through the scalar cache
     uint32_t* ere_lists_dev = nullptr;
     // developer switches, read ONCE at batch creation (getenv on every launch costs more than the launch itself)
-    bool no_lds_topo = false, no_fused_masks = false, slow_masks = false;
+    bool no_lds_topo = false, no_fused_masks = false, slow_masks = false, no_row_masks = false;
     uint32_t step_block_override = 0;
     uint8_t* arena = nullptr;       // every per-env column + bodies + init body, one allocation
     size_t arena_bytes = 0;
@@ -273,7 +273,7 @@ extern "C" int mcbs_batch_create(const mcbs_topology* topo, const mcbs_batch_cfg
     b->topo = topo;
     b->cfg = *cfg;
     b->no_lds_topo = getenv("MCBS_NO_LDS_TOPO") != nullptr; b->no_fused_masks = getenv("MCBS_NO_FUSED_MASKS") != nullptr;
-    b->slow_masks = getenv("MCBS_SLOW_MASKS") != nullptr;
+    b->slow_masks = getenv("MCBS_SLOW_MASKS") != nullptr; b->no_row_masks = getenv("MCBS_NO_ROW_MASKS") != nullptr;
     if (const char* ov = getenv("MCBS_STEP_BLOCK")) b->step_block_override = (uint32_t)atoi(ov);   // experiments only (64, 128 or 256)
     const uint32_t E = cfg->n_envs, N = h->n_nodes;
     DevState& S = b->S;
@@ -616,6 +616,8 @@ static int launch_obs(mcbs_batch* b, const mcbs_obs_buffers* o, hipStream_t st, 
     return launch_masks(b, &rest, st, env_mask, masks_only);
 }
 
+static inline bool getenv_rows_off(const mcbs_batch* b) { return b->no_row_masks; }
+
 template <int REGION>
 static int launch_region(mcbs_batch* b, int8_t* dst, size_t env_stride, size_t region_off, size_t len, hipStream_t st, const uint8_t* env_mask, bool masks_only) {
     const uint32_t Nm = b->cfg.maximum_node_count, Cm = b->cfg.maximum_total_credentials;
@@ -627,6 +629,21 @@ static int launch_region(mcbs_batch* b, int8_t* dst, size_t env_stride, size_t r
     const dim3 grid(b->S.E, (unsigned)((chunks + 255) / 256));
     if (grid.y > 65535u) return fail(MCBS_ELIMIT, "mask region too large for one launch");
     const uint32_t RL = REGION == 0 ? b->C.P * Cm : (REGION == 1 ? Nm * b->C.R : 0u), Cc = REGION == 0 ? Cm : RL;
+    if (W == 16 && REGION == 0 && RL % 16u == 0 && RL >= 16u && !b->slow_masks && !getenv_rows_off(b)) {
+        // whole rows of 16-byte chunks: pattern row + per-row on/off bytes in LDS (mcbs_obs.hip: mask_connect_rows_kernel)
+        const uint32_t cpr = RL / 16u, rows = Nm * Nm;
+        uint32_t rpb = 128u;                                          // rows per workgroup: >= 16 KB of output each
+        while (rpb * RL < 16384u && rpb < rows) rpb *= 2u;
+        const uint32_t lds = cpr * 16u + ((rpb + 15u) & ~15u);
+        if (lds <= 60000u) {
+            const uint32_t gx = (rows + rpb - 1u) / rpb;
+            uint32_t gy = b->S.E;
+            if ((uint64_t)gx * gy > (1u << 20)) gy = (1u << 20) / gx ? (1u << 20) / gx : 1u;
+            hipLaunchKernelGGL(mask_connect_rows_kernel, dim3(gx, gy), dim3(256), lds, st, b->S, b->digest, dst, env_stride, region_off,
+                               Nm, Cm, RL, rpb, env_mask, masks_only ? 0u : 1u);
+            return launch_ok("mask (rows)");
+        }
+    }
     if (W == 16 && REGION != 2 && RL >= 16u && len < (1ull << 31) && !b->slow_masks) {
         auto fd = [](uint32_t d) {   // n / d = (t + ((n - t) >> sh1)) >> sh2 with t = mulhi(n, mul)
             uint32_t l = 0;
