@@ -376,7 +376,8 @@ int  mcbs_defender_observe(mcbs_batch*, const mcbs_defender_obs* obs, void* stre
 int  mcbs_set_draw_tape(mcbs_batch*, const double* tape, uint32_t draws_per_step);
 
 /* Parity / debugging: canonical per-env state records (layout: mcbs_state_record below),
- * host buffers, synchronous. */
+ * host buffers, synchronous.  The record does not carry what only MCBS_DEFENDER_RANDOM_EVENTS mutates (vulnerability keys,
+ * service flags, firewall rule lists): mcbs_set_state puts those back to the topology's initial ones for the envs it writes. */
 size_t mcbs_state_record_bytes(const mcbs_batch*);
 int  mcbs_get_state(mcbs_batch*, void* host_buf, size_t nbytes);
 int  mcbs_set_state(mcbs_batch*, const void* host_buf, size_t nbytes);

@@ -864,6 +864,10 @@ extern "C" int mcbs_set_state(mcbs_batch* b, const void* host_buf, size_t nbytes
             if (ring) for (uint32_t s = 0; s < 16u; ++s) ring[((size_t)s * S.WT + w) * S.E + e] = 0;
         }
         uint8_t* eb = body + (size_t)e * S.body_stride;
+        if (b->cfg.defender_kind == MCBS_DEFENDER_RANDOM_EVENTS) {   // the canonical record does not carry the random-events overlay
+            const uint8_t* init = at(S.init_body);                   // (vulnerability keys, service bits, rule lists): back to the
+            memcpy(eb + b->C.ere_off_present, init + b->C.ere_off_present, S.body_stride - b->C.ere_off_present);   // topology's initial ones
+        }
         uint32_t owned = 0;
         const uint32_t dclk = h0[e].w >> 16;      // the defender clock is not part of the canonical record: keep the current phase
         for (uint32_t n = 0; n < S.N; ++n) {
