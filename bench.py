@@ -81,12 +81,23 @@ def main() -> int:
     if args.single_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    backend = args.backend
     if world > 1:
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if backend == "nccl":
+            try:
+                dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+                probe = torch.zeros(1, device=f"cuda:{local_rank}")
+                dist.all_reduce(probe)                      # RCCL communicators are created lazily: fail here, not in the timed region
+                torch.cuda.synchronize()
+            except Exception as exc:                        # the data path has no collective: only the timing barrier / MAX need one,
+                print(f"bench.py: RCCL unavailable ({exc}); timing collectives over gloo", file=sys.stderr)   # so gloo is enough
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                backend = "gloo"
+                dist.init_process_group("gloo")
         else:
-            dist.init_process_group(args.backend)
-    coll_dev = torch.device(f"cuda:{local_rank}") if args.backend == "nccl" else torch.device("cpu")
+            dist.init_process_group(backend)
+    coll_dev = torch.device(f"cuda:{local_rank}") if backend == "nccl" else torch.device("cpu")
 
     def barrier():
         if world > 1:
