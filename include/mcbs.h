@@ -375,6 +375,31 @@ int  mcbs_defender_observe(mcbs_batch*, const mcbs_defender_obs* obs, void* stre
  * step (scan draws first, then detection draws in consumption order). */
 int  mcbs_set_draw_tape(mcbs_batch*, const double* tape, uint32_t draws_per_step);
 
+/* Bookkeeping of marlon's AttackerEnvWrapper.step around the environment step (attack_wrapper.py:286-354), for every env in one
+ * launch: step / action counters, the reward modifier of an intercepted action, truncation at max_timesteps, episode returns.
+ * All pointers are device arrays of n_envs elements owned by the caller (a batched wrapper keeps them next to its observation). */
+typedef struct mcbs_wrapper_buffers {
+    const uint8_t* invalid;        /* in : from mcbs_decode_attacker_actions */
+    const float*   reward;         /* in : from mcbs_step / mcbs_step_observe */
+    const uint8_t* terminated;     /* in */
+    int32_t* timesteps;            /* in/out: wrapper steps of the current episode (invalid ones included) */
+    int64_t* valid_action_count;   /* in/out */
+    int64_t* invalid_action_count; /* in/out */
+    double*  episode_returns;      /* in/out: sum of the wrapper's rewards */
+    float*   last_cyber_reward;    /* out: the environment's own reward of this step (AttackerEnvWrapper.cyber_rewards[-1]) */
+    uint8_t* has_cyber_reward;     /* out: 1 */
+    float*   rewards;              /* out: reward + invalid * invalid_action_reward_modifier */
+    uint8_t* truncated;            /* out: timesteps >= max_timesteps */
+    uint8_t* dones;                /* out: terminated | truncated */
+    double*  episode_return_out;   /* out: copies for the info dict, taken before a reset clears the counters */
+    int32_t* episode_length_out;   /* out */
+    int32_t* n_done;               /* out: one int32, number of envs with dones != 0 (zeroed by the call) */
+} mcbs_wrapper_buffers;
+int  mcbs_attacker_wrapper_post(mcbs_batch*, const mcbs_wrapper_buffers* w, float invalid_action_reward_modifier, int32_t max_timesteps,
+                                void* stream);
+/* ... and the counters of the envs whose dones flag is set back to zero (what the wrapper's reset() does for them). */
+int  mcbs_attacker_wrapper_clear(mcbs_batch*, const mcbs_wrapper_buffers* w, void* stream);
+
 /* Parity / debugging: canonical per-env state records (layout: mcbs_state_record below),
  * host buffers, synchronous.  The record does not carry what only MCBS_DEFENDER_RANDOM_EVENTS mutates (vulnerability keys,
  * service flags, firewall rule lists): mcbs_set_state puts those back to the topology's initial ones for the envs it writes. */

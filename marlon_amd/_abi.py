@@ -36,6 +36,13 @@ class ObsBuffers(C.Structure):
         "nodes_privilegelevel", "mask_local", "mask_remote", "mask_connect", "mask_discrete")]
 
 
+class WrapperBuffers(C.Structure):
+    """mcbs_wrapper_buffers (include/mcbs.h): device arrays of AttackerEnvWrapper's per-env bookkeeping"""
+    _fields_ = [(n, C.c_void_p) for n in ("invalid", "reward", "terminated", "timesteps", "valid_action_count", "invalid_action_count",
+                                          "episode_returns", "last_cyber_reward", "has_cyber_reward", "rewards", "truncated", "dones",
+                                          "episode_return_out", "episode_length_out", "n_done")]
+
+
 class DefenderObs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("infected_nodes", "incoming_firewall_status", "outgoing_firewall_status", "services_status")]
 

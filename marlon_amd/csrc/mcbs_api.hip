@@ -716,6 +716,23 @@ extern "C" int mcbs_step_observe(mcbs_batch* b, const int32_t* actions, float* r
     return launch_step<2>(b, io, st, "step (defender phase)");
 }
 
+extern "C" int mcbs_attacker_wrapper_post(mcbs_batch* b, const mcbs_wrapper_buffers* w, float modifier, int32_t max_timesteps, void* stream) {
+    if (!b || !w) return fail(MCBS_EINVAL, "null argument");
+    const void* const* p = reinterpret_cast<const void* const*>(w);
+    for (size_t i = 0; i < sizeof(*w) / sizeof(void*); ++i) if (!p[i]) return fail(MCBS_EINVAL, "mcbs_wrapper_buffers: every array is required");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(w->n_done, 0, sizeof(int32_t), st));
+    hipLaunchKernelGGL(wrapper_post_kernel, dim3((b->S.E + 255) / 256), dim3(256), 0, st, b->S.E, *w, modifier, max_timesteps);
+    return launch_ok("wrapper post");
+}
+
+extern "C" int mcbs_attacker_wrapper_clear(mcbs_batch* b, const mcbs_wrapper_buffers* w, void* stream) {
+    if (!b || !w || !w->dones || !w->timesteps || !w->valid_action_count || !w->invalid_action_count || !w->episode_returns || !w->has_cyber_reward)
+        return fail(MCBS_EINVAL, "null argument");
+    hipLaunchKernelGGL(wrapper_clear_kernel, dim3((b->S.E + 255) / 256), dim3(256), 0, (hipStream_t)stream, b->S.E, *w);
+    return launch_ok("wrapper clear");
+}
+
 extern "C" int mcbs_step_info(mcbs_batch* b, const mcbs_info_buffers* info, void* stream) {
     if (!b || !info) return fail(MCBS_EINVAL, "null argument");
     StepIO io = make_io(b, nullptr, nullptr, nullptr, info);

@@ -97,4 +97,37 @@ __global__ __launch_bounds__(256) void decode_kernel(DevState S, const StepCfg* 
     invalid[e] = ok ? 0 : 1;
 }
 
+// AttackerEnvWrapper.step's bookkeeping (attack_wrapper.py:286-354) for the whole batch: one launch instead of ~20 element-wise ones
+__global__ __launch_bounds__(256) void wrapper_post_kernel(uint32_t E, mcbs_wrapper_buffers w, float modifier, int32_t max_timesteps) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    bool done = false;
+    if (e < E) {
+        const bool invalid = w.invalid[e] != 0;
+        const float r = w.reward[e];
+        const int32_t t = w.timesteps[e] + 1;
+        const float shaped = r + (invalid ? modifier : 0.0f);
+        const double ret = w.episode_returns[e] + (double)shaped;
+        const bool trunc = t >= max_timesteps;
+        done = (w.terminated[e] != 0) || trunc;
+        w.timesteps[e] = t;
+        if (invalid) w.invalid_action_count[e] += 1; else w.valid_action_count[e] += 1;
+        w.episode_returns[e] = ret;
+        w.last_cyber_reward[e] = r;
+        w.has_cyber_reward[e] = 1;
+        w.rewards[e] = shaped;
+        w.truncated[e] = trunc ? 1 : 0;
+        w.dones[e] = done ? 1 : 0;
+        w.episode_return_out[e] = ret;
+        w.episode_length_out[e] = t;
+    }
+    const uint64_t m = __ballot(done);
+    if (m && (threadIdx.x & 63u) == 0) atomicAdd(w.n_done, (int32_t)__popcll(m));
+}
+
+__global__ __launch_bounds__(256) void wrapper_clear_kernel(uint32_t E, mcbs_wrapper_buffers w) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E || !w.dones[e]) return;
+    w.timesteps[e] = 0; w.valid_action_count[e] = 0; w.invalid_action_count[e] = 0; w.episode_returns[e] = 0.0; w.has_cyber_reward[e] = 0;
+}
+
 } // namespace mcbs

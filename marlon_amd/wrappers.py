@@ -73,6 +73,14 @@ class AttackerVecEnv:
         self.episode_returns = t.zeros(n_envs, dtype=t.float64, device=dev)
         self.last_cyber_reward = t.zeros(n_envs, dtype=t.float32, device=dev)
         self.has_cyber_reward = t.zeros(n_envs, dtype=t.bool, device=dev)    # AttackerEnvWrapper.cyber_rewards is non-empty
+        # outputs of the fused bookkeeping launch (mcbs_attacker_wrapper_post) and its argument block
+        self._rewards = t.zeros(n_envs, dtype=t.float32, device=dev)
+        self._truncated = t.zeros(n_envs, dtype=t.uint8, device=dev)
+        self._dones = t.zeros(n_envs, dtype=t.uint8, device=dev)
+        self._ret_out = t.zeros(n_envs, dtype=t.float64, device=dev)
+        self._len_out = t.zeros(n_envs, dtype=t.int32, device=dev)
+        self._n_done = t.zeros(1, dtype=t.int32, device=dev)
+        self._wb = None
         self.reset()
 
     # -- observation plumbing --
@@ -117,34 +125,28 @@ class AttackerVecEnv:
         else:
             self.engine.decode_attacker_actions(multidiscrete=actions, actions_out=self._rows, invalid_out=self._invalid)
         reward, terminated = self.engine.step_observe(self._rows, self._obs)
-        invalid = self._invalid != 0
-        self.timesteps += 1
-        self.invalid_action_count += invalid
-        self.valid_action_count += ~invalid
-        self.last_cyber_reward = reward.clone()                                                   # AttackerEnvWrapper.cyber_rewards[-1]
-        rewards = reward + invalid.to(reward.dtype) * self.invalid_action_reward_modifier        # attack_wrapper.py:296,354
-        truncated = self.timesteps >= self.max_timesteps                                          # :350-352
-        terminated = terminated != 0
-        dones = terminated | truncated
-        self.episode_returns += rewards.double()
-        self.has_cyber_reward |= True
-        info = {"invalid_action": invalid, "cyber_step_executed": ~invalid,
+        # counters, reward modifier of intercepted actions (attack_wrapper.py:296,354), truncation (:350-352), episode returns:
+        # one launch for the whole batch
+        if self._wb is None:
+            from ._abi import WrapperBuffers
+            self._wb = WrapperBuffers(*[x.data_ptr() for x in (
+                self._invalid, reward, terminated, self.timesteps, self.valid_action_count, self.invalid_action_count, self.episode_returns,
+                self.last_cyber_reward, self.has_cyber_reward, self._rewards, self._truncated, self._dones, self._ret_out, self._len_out,
+                self._n_done)])
+        self.engine.wrapper_post(self._wb, self.invalid_action_reward_modifier, self.max_timesteps)
+        invalid = self._invalid.view(t.bool)
+        rewards, truncated, terminated = self._rewards.clone(), self._truncated.clone(), terminated.clone()
+        info = {"invalid_action": invalid.clone(), "cyber_step_executed": ~invalid,
                 "network_availability": self.engine.info["network_availability"], "step_count": self.engine.info["step_count"],
-                "episode_return": self.episode_returns.clone(), "episode_length": self.timesteps.clone()}
-        ended = dones.nonzero().squeeze(1) if self.auto_reset else None        # (one host sync per step, like dones.any() before)
-        if ended is not None and ended.numel():
+                "episode_return": self._ret_out.clone(), "episode_length": self._len_out.clone()}
+        if self.auto_reset and int(self._n_done.item()):      # (one host sync per step)
+            ended = self._dones.nonzero().squeeze(1)
             for k in self._obs:                       # terminal observation of the envs that ended only, not the whole batch
                 self._terminal[k].index_copy_(0, ended, self._obs[k].index_select(0, ended))
-            mask = dones.to(t.uint8)
-            self.engine.reset(mask)
-            self.engine.observe(self._obs, env_mask=mask)   # reset observation for the envs that ended; the others keep theirs
-            keep = ~dones
-            self.timesteps *= keep
-            self.valid_action_count *= keep
-            self.invalid_action_count *= keep
-            self.episode_returns *= keep
-            self.has_cyber_reward &= keep
-        return self.observation, rewards, terminated.to(t.uint8), truncated.to(t.uint8), info
+            self.engine.reset(self._dones)
+            self.engine.observe(self._obs, env_mask=self._dones)   # reset observation for the envs that ended; the others keep theirs
+            self.engine.wrapper_clear(self._wb)
+        return self.observation, rewards, terminated, truncated, info
 
     def close(self) -> None:
         self.engine.close()
