@@ -28,8 +28,10 @@ from ._abi import EnvSpec
 from .cyberbattle_env import (SCALAR_KEYS, AttackerGoal, DefenderConstraint, DefenderGoal, spec_from_kwargs)
 from .flatten import FlatTopology, flatten
 
+# what the engine writes; the three separate action masks of marlon's observation dict are VIEWS into mask_discrete
+# (connect | local | remote, action_masking.py:96-110): the same bytes, written once
 FLAT_FIELDS = ["scalars", "leaked_credentials", "credential_cache_matrix", "discovered_nodes_properties",
-               "nodes_privilegelevel", "mask_local", "mask_remote", "mask_connect", "mask_discrete"]
+               "nodes_privilegelevel", "mask_discrete"]
 
 
 class AttackerVecEnv:
@@ -65,6 +67,7 @@ class AttackerVecEnv:
         dev = self.engine.device
         self._obs = self.engine.alloc_obs(FLAT_FIELDS)
         self._terminal = {k: t.zeros_like(v) for k, v in self._obs.items()}
+        self._mask_split = (N * N * P * Cm, N * L, (N, N, P, Cm), (N, L), (N, N, R))
         self._rows = t.zeros((n_envs, 5), dtype=t.int32, device=dev)
         self._invalid = t.zeros(n_envs, dtype=t.uint8, device=dev)
         self.timesteps = t.zeros(n_envs, dtype=t.int32, device=dev)
@@ -85,7 +88,10 @@ class AttackerVecEnv:
 
     # -- observation plumbing --
     def _public(self, obs: Dict[str, object]) -> Dict[str, object]:
-        out = {"local_vulnerability": obs["mask_local"], "remote_vulnerability": obs["mask_remote"], "connect": obs["mask_connect"],
+        M, ML, s_connect, s_local, s_remote = self._mask_split
+        flat = obs["mask_discrete"]
+        out = {"local_vulnerability": flat[:, M:M + ML].unflatten(1, s_local), "remote_vulnerability": flat[:, M + ML:].unflatten(1, s_remote),
+               "connect": flat[:, :M].unflatten(1, s_connect),
                "leaked_credentials": obs["leaked_credentials"].reshape(self.num_envs, -1),
                "credential_cache_matrix": obs["credential_cache_matrix"].reshape(self.num_envs, -1),
                "discovered_nodes_properties": obs["discovered_nodes_properties"].reshape(self.num_envs, -1),
