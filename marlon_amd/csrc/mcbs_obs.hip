@@ -278,17 +278,82 @@ __global__ __launch_bounds__(256) void obs_small_kernel(DevState S, Topo T, cons
         // three regions are streamed as dwords.
         const uint32_t RL = C.P * O.Cmax, R = C.R;
         const uint32_t M = rows * RL, ML = Nm * L, MR = rows * R;
-        uint32_t* out = reinterpret_cast<uint32_t*>(O.mask_discrete + (size_t)e * (M + ML + MR));
+        int8_t* base = O.mask_discrete + (size_t)e * (M + ML + MR);
+        const uint32_t cpr = RL >> 4;
+        // value of byte b of the env's flat mask (connect | local | remote), for the few bytes not covered by whole 16-byte chunks
+        auto byte_at = [&](uint32_t b) -> uint32_t {
+            if (b < M) { const uint32_t q = b / RL, r = b - q * RL; return (uint32_t)(row_on(q) && (r % O.Cmax) < n_creds); }
+            b -= M;
+            if (b < ML) {
+                const uint32_t i = b / L, l = b - i * L;
+                return (uint32_t)(!blank && i < n_disc && ((own_ext[(i >> 6) & 3u] >> (i & 63u)) & 1ull) && ((st.lmask[i & 255u] >> l) & 1u));
+            }
+            return (uint32_t)row_on((b - ML) / R);
+        };
+        if ((RL & 15u) == 0u && cpr <= 64u && M >= 64u) {
+            // Row length a multiple of 16 (Chain-10: 96): env bases are only 4-byte aligned (the flat length, 14 172, is not a multiple of
+            // 16), so the first 16-byte boundary sits h = 0 / 4 / 8 / 12 bytes into the env.  From there every chunk starts h bytes into a
+            // 16-byte column of its row: lane j builds the SHIFTED pattern chunk j (bytes h + 16 j ... of the row followed by itself), and
+            // only the last chunk of a row straddles into the next one (its upper h bytes take that row's on / off).
+            const uint32_t h = (16u - (uint32_t)(reinterpret_cast<uintptr_t>(base) & 15u)) & 15u, Cc = O.Cmax;
+            __builtin_amdgcn_wave_barrier();               // (an earlier pattern may still be in use by other lanes)
+            if (lane < cpr) {
+                uint32_t r = h + lane * 16u, w[4] = {0, 0, 0, 0};
+                if (r >= RL) r -= RL;
+                uint32_t c = r % Cc;
+#pragma unroll
+                for (uint32_t i = 0; i < 16u; ++i) {
+                    w[i >> 2] |= (uint32_t)(c < n_creds) << (8u * (i & 3u));
+                    r += 1u; c += 1u;
+                    if (c == Cc) c = 0u;
+                    if (r == RL) { r = 0u; c = 0u; }
+                }
+                st.pat[lane] = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+            if (lane * 4u < h) {                             // head: the h bytes before the first aligned chunk (row 0)
+                uint32_t v = 0;
+#pragma unroll
+                for (uint32_t b = 0; b < 4u; ++b) v |= byte_at(lane * 4u + b) << (8u * b);
+                reinterpret_cast<uint32_t*>(base)[lane] = v;
+            }
+            const uint32_t nchunks = (M - h) >> 4, dq = 64u / cpr, dj = 64u - dq * cpr;
+            uint4* out16 = reinterpret_cast<uint4*>(base + h);
+            uint32_t q = (h + lane * 16u) / RL, j = ((h + lane * 16u) - q * RL - h) >> 4;
+            // bytes [0, 16 - h) of a straddling chunk belong to row q, the rest to row q + 1
+            const uint32_t nb = 16u - h;
+            uint32_t keep[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k) keep[k] = nb >= 4u * (k + 1u) ? 0xFFFFFFFFu : (nb <= 4u * k ? 0u : ((1u << (8u * (nb - 4u * k))) - 1u));
+            for (uint32_t c = lane; c < nchunks; c += 64u) {
+                const uint4 p = st.pat[j];
+                const uint32_t a = row_on(q) ? 0xFFFFFFFFu : 0u;
+                uint4 v = make_uint4(p.x & a, p.y & a, p.z & a, p.w & a);
+                if (h && j == cpr - 1u) {
+                    const uint32_t nx = row_on(q + 1u) ? 0xFFFFFFFFu : 0u;
+                    v = make_uint4(p.x & ((a & keep[0]) | (nx & ~keep[0])), p.y & ((a & keep[1]) | (nx & ~keep[1])),
+                                   p.z & ((a & keep[2]) | (nx & ~keep[2])), p.w & ((a & keep[3]) | (nx & ~keep[3])));
+                }
+                out16[c] = v;
+                j += dj; q += dq;
+                if (j >= cpr) { j -= cpr; q += 1u; }
+            }
+            const uint32_t t0 = h + (nchunks << 4), D = M + ML + MR;    // tail: the rest of connect (< 16 bytes), local, remote
+            for (uint32_t b0 = t0 + lane * 4u; b0 < D; b0 += 256u) {
+                uint32_t v = 0;
+#pragma unroll
+                for (uint32_t b = 0; b < 4u; ++b) v |= byte_at(b0 + b) << (8u * b);
+                *reinterpret_cast<uint32_t*>(base + b0) = v;
+            }
+        } else {
+        uint32_t* out = reinterpret_cast<uint32_t*>(base);
         stream_connect_dwords(out);
         out += M >> 2;
         for (uint32_t i0 = lane * 4u; i0 < ML; i0 += 256u) {      // local[i][l], same rule as mask_local
             uint32_t v = 0;
 #pragma unroll
-            for (uint32_t b = 0; b < 4u; ++b) {
-                const uint32_t idx = i0 + b, i = idx / L, l = idx - i * L;
-                const bool bit = !blank && i < n_disc && ((own_ext[(i >> 6) & 3u] >> (i & 63u)) & 1ull) && ((st.lmask[i & 255u] >> l) & 1u);
-                v |= (uint32_t)bit << (8u * b);
-            }
+            for (uint32_t b = 0; b < 4u; ++b) v |= byte_at(M + i0 + b) << (8u * b);
             out[i0 >> 2] = v;
         }
         out += ML >> 2;
@@ -297,6 +362,7 @@ __global__ __launch_bounds__(256) void obs_small_kernel(DevState S, Topo T, cons
 #pragma unroll
             for (uint32_t b = 0; b < 4u; ++b) v |= (uint32_t)row_on((i0 + b) / R) << (8u * b);
             out[i0 >> 2] = v;
+        }
         }
     }
 }
