@@ -400,6 +400,33 @@ int  mcbs_attacker_wrapper_post(mcbs_batch*, const mcbs_wrapper_buffers* w, floa
 /* ... and the counters of the envs whose dones flag is set back to zero (what the wrapper's reset() does for them). */
 int  mcbs_attacker_wrapper_clear(mcbs_batch*, const mcbs_wrapper_buffers* w, void* stream);
 
+/* The reward shaping of marlon's DefenderEnvWrapper.step (defend_wrapper.py:228-282) around mcbs_defender_step, for every env in one
+ * launch and in the wrapper's own order of double-precision operations: invalid-action penalty, minus the attacker's last environment
+ * reward, loss_reward when availability first drops below maintain_sla (terminating if reset_on_constraint_broken), a penalty
+ * proportional to the worsening while breached, winning_reward when the attacker is evicted; truncation at max_timesteps. */
+typedef struct mcbs_defender_wrapper_buffers {
+    const uint8_t* valid;          /* in : mcbs_defender_step outputs */
+    const double*  availability;   /* in */
+    const uint8_t* evicted;        /* in */
+    const uint8_t* attacker_has_cyber_reward;  /* in : the attacker wrapper's buffers (mcbs_wrapper_buffers) */
+    const float*   attacker_last_cyber_reward; /* in */
+    int32_t* timesteps;            /* in/out */
+    int64_t* valid_action_count;   /* in/out */
+    int64_t* invalid_action_count; /* in/out */
+    uint8_t* has_breached_sla;     /* in/out */
+    double*  prev_availability;    /* in/out */
+    double*  reward;               /* out */
+    uint8_t* terminated;           /* out */
+    uint8_t* truncated;            /* out */
+    uint8_t* breached;             /* out: availability < maintain_sla */
+    uint8_t* won;                  /* out: attacker evicted */
+} mcbs_defender_wrapper_buffers;
+typedef struct mcbs_defender_wrapper_cfg {
+    double invalid_action_penalty, loss_reward, sla_worsening_penalty_scale, maintain_sla, winning_reward;
+    int32_t reset_on_constraint_broken, max_timesteps;
+} mcbs_defender_wrapper_cfg;
+int  mcbs_defender_wrapper_post(mcbs_batch*, const mcbs_defender_wrapper_buffers* w, const mcbs_defender_wrapper_cfg* cfg, void* stream);
+
 /* Parity / debugging: canonical per-env state records (layout: mcbs_state_record below),
  * host buffers, synchronous.  The record does not carry what only MCBS_DEFENDER_RANDOM_EVENTS mutates (vulnerability keys,
  * service flags, firewall rule lists): mcbs_set_state puts those back to the topology's initial ones for the envs it writes. */

@@ -43,6 +43,19 @@ class WrapperBuffers(C.Structure):
                                           "episode_return_out", "episode_length_out", "n_done")]
 
 
+class DefenderWrapperBuffers(C.Structure):
+    """mcbs_defender_wrapper_buffers (include/mcbs.h)"""
+    _fields_ = [(n, C.c_void_p) for n in ("valid", "availability", "evicted", "attacker_has_cyber_reward", "attacker_last_cyber_reward",
+                                          "timesteps", "valid_action_count", "invalid_action_count", "has_breached_sla", "prev_availability",
+                                          "reward", "terminated", "truncated", "breached", "won")]
+
+
+class DefenderWrapperCfg(C.Structure):
+    _fields_ = [("invalid_action_penalty", C.c_double), ("loss_reward", C.c_double), ("sla_worsening_penalty_scale", C.c_double),
+                ("maintain_sla", C.c_double), ("winning_reward", C.c_double), ("reset_on_constraint_broken", C.c_int32),
+                ("max_timesteps", C.c_int32)]
+
+
 class DefenderObs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("infected_nodes", "incoming_firewall_status", "outgoing_firewall_status", "services_status")]
 

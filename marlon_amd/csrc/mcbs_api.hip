@@ -733,6 +733,14 @@ extern "C" int mcbs_attacker_wrapper_clear(mcbs_batch* b, const mcbs_wrapper_buf
     return launch_ok("wrapper clear");
 }
 
+extern "C" int mcbs_defender_wrapper_post(mcbs_batch* b, const mcbs_defender_wrapper_buffers* w, const mcbs_defender_wrapper_cfg* cfg, void* stream) {
+    if (!b || !w || !cfg) return fail(MCBS_EINVAL, "null argument");
+    const void* const* p = reinterpret_cast<const void* const*>(w);
+    for (size_t i = 0; i < sizeof(*w) / sizeof(void*); ++i) if (!p[i]) return fail(MCBS_EINVAL, "mcbs_defender_wrapper_buffers: every array is required");
+    hipLaunchKernelGGL(defender_wrapper_post_kernel, dim3((b->S.E + 255) / 256), dim3(256), 0, (hipStream_t)stream, b->S.E, *w, *cfg);
+    return launch_ok("defender wrapper post");
+}
+
 extern "C" int mcbs_step_info(mcbs_batch* b, const mcbs_info_buffers* info, void* stream) {
     if (!b || !info) return fail(MCBS_EINVAL, "null argument");
     StepIO io = make_io(b, nullptr, nullptr, nullptr, info);

@@ -22,7 +22,7 @@ LIB_PATH = os.path.join(_HERE, "libmcbs.so")
 EXPORTS = [
     "mcbs_last_error", "mcbs_abi_version", "mcbs_topology_create", "mcbs_topology_destroy", "mcbs_batch_create",
     "mcbs_batch_destroy", "mcbs_reset", "mcbs_step", "mcbs_step_observe", "mcbs_observe", "mcbs_observe_masked", "mcbs_action_mask", "mcbs_step_info",
-    "mcbs_step_many", "mcbs_rollout_random", "mcbs_attacker_wrapper_post", "mcbs_attacker_wrapper_clear", "mcbs_sample_actions", "mcbs_decode_attacker_actions", "mcbs_defender_step", "mcbs_defender_observe", "mcbs_set_draw_tape", "mcbs_state_record_bytes", "mcbs_get_state", "mcbs_set_state",
+    "mcbs_step_many", "mcbs_rollout_random", "mcbs_attacker_wrapper_post", "mcbs_attacker_wrapper_clear", "mcbs_defender_wrapper_post", "mcbs_sample_actions", "mcbs_decode_attacker_actions", "mcbs_defender_step", "mcbs_defender_observe", "mcbs_set_draw_tape", "mcbs_state_record_bytes", "mcbs_get_state", "mcbs_set_state",
     "mcbs_timing_enable", "mcbs_timing_read",
 ]
 
@@ -58,6 +58,7 @@ def load_library(path: Optional[str] = None):
     lib.mcbs_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(InfoBuffers), C.c_void_p]
     lib.mcbs_step_many.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     lib.mcbs_attacker_wrapper_post.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int32, C.c_void_p]
+    lib.mcbs_defender_wrapper_post.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.mcbs_attacker_wrapper_clear.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.mcbs_rollout_random.argtypes = [C.c_void_p, C.c_int32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.mcbs_step_observe.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(InfoBuffers),
@@ -235,6 +236,10 @@ class BatchEngine:
         """AttackerEnvWrapper.step's bookkeeping for every env in one launch; `bufs` is a _abi.WrapperBuffers of device pointers."""
         _check(self.lib, self.lib.mcbs_attacker_wrapper_post(self._h, C.byref(bufs), float(modifier), int(max_timesteps), self._stream()),
                "mcbs_attacker_wrapper_post")
+
+    def defender_wrapper_post(self, bufs, cfg) -> None:
+        """DefenderEnvWrapper.step's reward shaping for every env in one launch (_abi.DefenderWrapperBuffers / DefenderWrapperCfg)."""
+        _check(self.lib, self.lib.mcbs_defender_wrapper_post(self._h, C.byref(bufs), C.byref(cfg), self._stream()), "mcbs_defender_wrapper_post")
 
     def wrapper_clear(self, bufs) -> None:
         _check(self.lib, self.lib.mcbs_attacker_wrapper_clear(self._h, C.byref(bufs), self._stream()), "mcbs_attacker_wrapper_clear")

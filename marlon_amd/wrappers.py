@@ -191,6 +191,7 @@ class DefenderVecEnv:
         self.prev_availability = t.ones(E, dtype=t.float64, device=dev)
         self.valid_action_count = t.zeros(E, dtype=t.int64, device=dev)
         self.invalid_action_count = t.zeros(E, dtype=t.int64, device=dev)
+        self._wb = None
         self.reset()
 
     @property
@@ -207,31 +208,27 @@ class DefenderVecEnv:
         self.valid_action_count *= keep
         self.invalid_action_count *= keep
         self.has_breached_sla &= keep
-        self.prev_availability = t.where(keep, self.prev_availability, avail)
+        self.prev_availability.copy_(t.where(keep, self.prev_availability, avail))    # in place: the fused shaping launch holds its address
         return self._obs
 
     def step(self, actions):
         """-> (observation dict, reward f64 [E], terminated u8 [E], truncated u8 [E], info)."""
         t = self.torch
         valid, avail, evicted = self.engine.defender_step(actions, self._obs)
-        valid = valid != 0
-        self.valid_action_count += valid
-        self.invalid_action_count += ~valid
-        reward = (~valid).double() * self.invalid_action_penalty
-        reward = reward - t.where(self.attacker.has_cyber_reward, self.attacker.last_cyber_reward.double(), t.zeros_like(reward))
-        worsening = self.prev_availability - avail
-        breached = avail < self.maintain_sla
-        first = breached & ~self.has_breached_sla
-        reward = reward + first.double() * self.loss_reward
-        again = breached & self.has_breached_sla & (worsening > 0)
-        reward = reward + t.where(again, -self.sla_worsening_penalty_scale * worsening, t.zeros_like(reward))
-        terminated = first if self.reset_on_constraint_broken else t.zeros_like(first)
-        self.has_breached_sla = breached
-        self.prev_availability = avail.clone()
-        won = evicted != 0                                                                   # defender goal: attacker evicted
-        reward = t.where(won, t.full_like(reward, self.winning_reward), reward)
-        terminated = terminated | won
-        self.timesteps += 1
-        truncated = self.timesteps >= self.max_timesteps
-        info = {"valid_action": valid, "network_availability": avail.clone(), "sla_breached": breached, "defender_won": won}
-        return self._obs, reward, terminated.to(t.uint8), truncated.to(t.uint8), info
+        if self._wb is None:        # reward shaping (defend_wrapper.py:228-282) for the whole batch in one launch
+            from ._abi import DefenderWrapperBuffers, DefenderWrapperCfg
+            E, dev = self.num_envs, self.engine.device
+            self._out = dict(reward=t.zeros(E, dtype=t.float64, device=dev), terminated=t.zeros(E, dtype=t.uint8, device=dev),
+                             truncated=t.zeros(E, dtype=t.uint8, device=dev), breached=t.zeros(E, dtype=t.uint8, device=dev),
+                             won=t.zeros(E, dtype=t.uint8, device=dev))
+            self._wb = DefenderWrapperBuffers(*[x.data_ptr() for x in (
+                valid, avail, evicted, self.attacker.has_cyber_reward, self.attacker.last_cyber_reward, self.timesteps, self.valid_action_count,
+                self.invalid_action_count, self.has_breached_sla, self.prev_availability, self._out["reward"], self._out["terminated"],
+                self._out["truncated"], self._out["breached"], self._out["won"])])
+            self._wc = DefenderWrapperCfg(self.invalid_action_penalty, self.loss_reward, self.sla_worsening_penalty_scale, self.maintain_sla,
+                                          self.winning_reward, int(self.reset_on_constraint_broken), self.max_timesteps)
+        self.engine.defender_wrapper_post(self._wb, self._wc)
+        reward, terminated, truncated = self._out["reward"].clone(), self._out["terminated"].clone(), self._out["truncated"].clone()
+        info = {"valid_action": valid.view(t.bool).clone(), "network_availability": avail.clone(), "sla_breached": self._out["breached"].view(t.bool).clone(),
+                "defender_won": self._out["won"].view(t.bool).clone()}
+        return self._obs, reward, terminated, truncated, info
