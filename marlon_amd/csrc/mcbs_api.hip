@@ -20,6 +20,18 @@ using namespace mcbs;
 
 static thread_local char g_err[512] = "";
 
+// Calls that must address a particular device (allocation, synchronous copies) select it for their own duration only: the
+// caller's current device (PyTorch's, in a single process driving several GPUs) is put back on every exit path.
+struct DeviceGuard {
+    int prev = -1;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) err = hipSetDevice(device); else prev = -1;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 static int fail(int code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -134,6 +146,20 @@ extern "C" int mcbs_topology_create(const void* blob, size_t nbytes, int32_t dev
         if (tr[i].node >= h->n_nodes || tr[i].cred >= h->n_cred_strings || tr[i].port >= h->n_ports)
             return fail(MCBS_EINVAL, "triple %u out of range", i);
     if ((rc = check_section(h, h->off_fw_list0, 2u * (size_t)h->n_fw_lists, "fw_list0"))) return rc;
+    if ((rc = check_section(h, h->off_fw_range, 2u * sizeof(uint16_t) * (size_t)h->n_fw_lists, "fw_range"))) return rc;
+    if ((rc = check_section(h, h->off_fw_rule, sizeof(mcbs_fw_rule) * (size_t)h->n_fw_rules, "fw_rule"))) return rc;
+    if (h->n_names > 256u) return fail(MCBS_ELIMIT, "more than 256 firewall port names");
+    {   // every rule list lies inside the rule array and every rule names a known port (mcbs_batch_create and the random-events
+        // kernels index with these)
+        const uint16_t* fr = reinterpret_cast<const uint16_t*>(b + h->off_fw_range);
+        const mcbs_fw_rule* fwr = reinterpret_cast<const mcbs_fw_rule*>(b + h->off_fw_rule);
+        for (uint32_t l = 0; l < h->n_fw_lists; ++l)
+            if ((uint32_t)fr[2 * l] + fr[2 * l + 1] > h->n_fw_rules) return fail(MCBS_EINVAL, "firewall rule list %u out of range", l);
+        for (uint32_t i = 0; i < h->n_fw_rules; ++i)
+            if (fwr[i].name >= h->n_names) return fail(MCBS_EINVAL, "firewall rule %u: port name out of range", i);
+        for (int i = 0; i < 6; ++i)
+            if (h->rule_port[i] != 0xFFu && h->rule_port[i] >= h->n_ports) return fail(MCBS_EINVAL, "rule_port[%d] out of range", i);
+    }
     for (uint32_t n = 0; n < h->n_nodes; ++n)
         if ((ns[n].fw_lists & 0xFFFFu) >= h->n_fw_lists || (ns[n].fw_lists >> 16) >= h->n_fw_lists) return fail(MCBS_EINVAL, "node %u: firewall list id", n);
     if (h->off_ere) {          // ExternalRandomEvents tables: every index a kernel will use as a bit position or an array subscript
@@ -216,7 +242,8 @@ extern "C" int mcbs_topology_create(const void* blob, size_t nbytes, int32_t dev
             }
         memcpy(hb + L.triple, tr, sizeof(mcbs_triple) * h->n_triples);
     }
-    hipError_t e = hipSetDevice(device);
+    DeviceGuard guard(device);
+    hipError_t e = guard.err;
     if (e == hipSuccess) e = hipMalloc(&t->dev, nbytes);
     if (e == hipSuccess) e = hipMemcpy(t->dev, blob, nbytes, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc(&t->hot_dev, t->hot_host.size());
@@ -233,7 +260,8 @@ extern "C" int mcbs_topology_create(const void* blob, size_t nbytes, int32_t dev
 
 extern "C" void mcbs_topology_destroy(mcbs_topology* t) {
     if (!t) return;
-    if (t->dev) { (void)hipSetDevice(t->device); (void)hipFree(t->dev); }
+    DeviceGuard guard(t->device);
+    if (t->dev) (void)hipFree(t->dev);
     if (t->hot_dev) (void)hipFree(t->hot_dev);
     delete t;
 }
@@ -337,7 +365,8 @@ extern "C" int mcbs_batch_create(const mcbs_topology* topo, const mcbs_batch_cfg
     const size_t o_body = take((size_t)S.body_stride * E + 64);   // + 64: packed batches fetch a fixed 64 bytes of rows per env
     b->arena_bytes = off;
 
-    hipError_t e = hipSetDevice(cfg->device);
+    DeviceGuard guard(cfg->device);
+    hipError_t e = guard.err;
     if (e == hipSuccess) e = hipMalloc(&b->arena, b->arena_bytes);
     if (e != hipSuccess) { delete b; return fail(MCBS_EHIP, "state allocation of %zu bytes failed: %s", off, hipGetErrorString(e)); }
     uint8_t* a = b->arena;
@@ -425,7 +454,7 @@ extern "C" int mcbs_batch_create(const mcbs_topology* topo, const mcbs_batch_cfg
 
 extern "C" void mcbs_batch_destroy(mcbs_batch* b) {
     if (!b) return;
-    (void)hipSetDevice(b->cfg.device);
+    DeviceGuard guard(b->cfg.device);
     for (hipEvent_t ev : b->ev) (void)hipEventDestroy(ev);
     if (b->arena) (void)hipFree(b->arena);
     if (b->C_dev) (void)hipFree(b->C_dev);
@@ -493,7 +522,7 @@ static int timing_end(mcbs_batch* b, hipStream_t st, size_t slot) {
 // Kernel variant: words per set kept in registers (1, 2 or 4), whether the topology tables fit the LDS budget, and
 // whether an in-env defender is configured (its code and loads are compiled out otherwise).
 template <int PHASE, int WT, int DEF, bool MANY = false>
-static void launch_step_v(mcbs_batch* b, const StepIO& io, hipStream_t st) {
+static void launch_step_v(mcbs_batch* b, const StepIO& io, hipStream_t st, const RollArgs& roll = RollArgs{}) {
     const uint32_t E = b->S.E, lds = b->C.hot_bytes;
     if (lds <= 60000u && !b->no_lds_topo) {
         // workgroup size: as large as still leaves one workgroup per CU (256) — every workgroup stages its own copy of the hot
@@ -502,28 +531,30 @@ static void launch_step_v(mcbs_batch* b, const StepIO& io, hipStream_t st) {
         uint32_t block = lds <= 8192u ? 64u : 256u;
         while (block < 256u && E / (block * 2u) >= 256u) block *= 2u;
         if (b->step_block_override) block = b->step_block_override;
-        hipLaunchKernelGGL((step_kernel<PHASE, WT, true, DEF, MANY>), dim3((E + block - 1) / block), dim3(block), lds + (b->S.wide ? block * b->S.TW * 8u : 0u), st,
-                           b->S, b->T, b->C_dev, io);
+        const uint32_t shm = lds + (b->S.wide ? block * b->S.TW * 8u : 0u);
+        if constexpr (MANY) hipLaunchKernelGGL((step_many_kernel<WT, true, DEF>), dim3((E + block - 1) / block), dim3(block), shm, st, b->S, b->T, b->C_dev, io, roll);
+        else hipLaunchKernelGGL((step_kernel<PHASE, WT, true, DEF>), dim3((E + block - 1) / block), dim3(block), shm, st, b->S, b->T, b->C_dev, io);
     } else {
-        hipLaunchKernelGGL((step_kernel<PHASE, WT, false, DEF, MANY>), dim3((E + 127) / 128), dim3(128), b->S.wide ? 128u * b->S.TW * 8u : 0u, st,
-                           b->S, b->T, b->C_dev, io);
+        const uint32_t shm = b->S.wide ? 128u * b->S.TW * 8u : 0u;
+        if constexpr (MANY) hipLaunchKernelGGL((step_many_kernel<WT, false, DEF>), dim3((E + 127) / 128), dim3(128), shm, st, b->S, b->T, b->C_dev, io, roll);
+        else hipLaunchKernelGGL((step_kernel<PHASE, WT, false, DEF>), dim3((E + 127) / 128), dim3(128), shm, st, b->S, b->T, b->C_dev, io);
     }
 }
 
 template <int PHASE, int WT, bool MANY = false>
-static void launch_step_nw(mcbs_batch* b, const StepIO& io, hipStream_t st) {
-    if (b->cfg.defender_kind == MCBS_DEFENDER_SCAN_AND_REIMAGE) launch_step_v<PHASE, WT, MCBS_DEFENDER_SCAN_AND_REIMAGE, MANY>(b, io, st);
-    else if (b->cfg.defender_kind == MCBS_DEFENDER_RANDOM_EVENTS) launch_step_v<PHASE, WT, MCBS_DEFENDER_RANDOM_EVENTS, MANY>(b, io, st);
-    else if (b->cfg.defender_kind == MCBS_DEFENDER_EXTERNAL) launch_step_v<PHASE, WT, MCBS_DEFENDER_EXTERNAL, MANY>(b, io, st);
-    else launch_step_v<PHASE, WT, MCBS_DEFENDER_NONE, MANY>(b, io, st);
+static void launch_step_nw(mcbs_batch* b, const StepIO& io, hipStream_t st, const RollArgs& roll) {
+    if (b->cfg.defender_kind == MCBS_DEFENDER_SCAN_AND_REIMAGE) launch_step_v<PHASE, WT, MCBS_DEFENDER_SCAN_AND_REIMAGE, MANY>(b, io, st, roll);
+    else if (b->cfg.defender_kind == MCBS_DEFENDER_RANDOM_EVENTS) launch_step_v<PHASE, WT, MCBS_DEFENDER_RANDOM_EVENTS, MANY>(b, io, st, roll);
+    else if (b->cfg.defender_kind == MCBS_DEFENDER_EXTERNAL) launch_step_v<PHASE, WT, MCBS_DEFENDER_EXTERNAL, MANY>(b, io, st, roll);
+    else launch_step_v<PHASE, WT, MCBS_DEFENDER_NONE, MANY>(b, io, st, roll);
 }
 
 template <int PHASE, bool MANY = false>
-static int launch_step(mcbs_batch* b, const StepIO& io, hipStream_t st, const char* what) {
-    if (b->S.packed) launch_step_nw<PHASE, 0, MANY>(b, io, st);       // WT 0: packed sets (one word of registers each)
-    else if (b->S.WT == 1) launch_step_nw<PHASE, 1, MANY>(b, io, st);
-    else if (b->S.WT == 2) launch_step_nw<PHASE, 2, MANY>(b, io, st);
-    else launch_step_nw<PHASE, 4, MANY>(b, io, st);
+static int launch_step(mcbs_batch* b, const StepIO& io, hipStream_t st, const char* what, const RollArgs& roll = RollArgs{}) {
+    if (b->S.packed) launch_step_nw<PHASE, 0, MANY>(b, io, st, roll);       // WT 0: packed sets (one word of registers each)
+    else if (b->S.WT == 1) launch_step_nw<PHASE, 1, MANY>(b, io, st, roll);
+    else if (b->S.WT == 2) launch_step_nw<PHASE, 2, MANY>(b, io, st, roll);
+    else launch_step_nw<PHASE, 4, MANY>(b, io, st, roll);
     return launch_ok(what);
 }
 
@@ -569,17 +600,12 @@ extern "C" int mcbs_rollout_random(mcbs_batch* b, int32_t valid, uint64_t seed, 
     if (b->cfg.rng_kind == MCBS_RNG_TAPE && b->cfg.defender_kind != MCBS_DEFENDER_NONE)
         return fail(MCBS_ESTATE, "mcbs_rollout_random needs the Philox generator: a draw tape holds one step's draws");
     hipStream_t st = (hipStream_t)stream;
-    struct { uint32_t mode, nmax, cmax, pad; uint64_t seed, step0; } roll = { valid ? 2u : 1u, b->cfg.maximum_node_count,
-                                                                             b->cfg.maximum_total_credentials, 0u, seed, first_step };
-    static_assert(offsetof(StepCfg, roll_step0) - offsetof(StepCfg, roll_mode) == 24, "roll block layout");
-    uint8_t* dst = reinterpret_cast<uint8_t*>(b->C_dev) + offsetof(StepCfg, roll_mode);
-    HIP_TRY(hipMemcpyAsync(dst, &roll, 32, hipMemcpyHostToDevice, st));
+    RollArgs roll;
+    roll.mode = valid ? 2u : 1u; roll.nmax = b->cfg.maximum_node_count; roll.cmax = b->cfg.maximum_total_credentials;
+    roll.seed = seed; roll.step0 = first_step;
     StepIO io = make_io(b, actions_out, reward, terminated, nullptr);
     io.n_steps = n_steps;
-    int rc = launch_step<0, true>(b, io, st, "rollout");
-    const uint32_t off = 0;
-    HIP_TRY(hipMemcpyAsync(dst, &off, 4, hipMemcpyHostToDevice, st));     // later mcbs_step_many launches read their actions again
-    return rc;
+    return launch_step<0, true>(b, io, st, "rollout", roll);   // the random agent's parameters are kernel arguments: no host copy, no shared state
 }
 
 static int launch_masks(mcbs_batch* b, const mcbs_obs_buffers* o, hipStream_t st, const uint8_t* env_mask, bool masks_only);
@@ -803,7 +829,8 @@ extern "C" int mcbs_get_state(mcbs_batch* b, void* host_buf, size_t nbytes) {
     const size_t rb = mcbs_state_record_bytes(b);
     const DevState& S = b->S;
     if (nbytes < rb * S.E) return fail(MCBS_EINVAL, "state buffer too small: need %zu bytes", rb * S.E);
-    HIP_TRY(hipSetDevice(b->cfg.device));
+    DeviceGuard guard(b->cfg.device);
+    HIP_TRY(guard.err);
     HIP_TRY(hipDeviceSynchronize());
     std::vector<uint8_t> host(b->arena_bytes);
     HIP_TRY(hipMemcpy(host.data(), b->arena, b->arena_bytes, hipMemcpyDeviceToHost));
@@ -859,7 +886,8 @@ extern "C" int mcbs_set_state(mcbs_batch* b, const void* host_buf, size_t nbytes
     const DevState& S = b->S;
     if (nbytes < rb * S.E) return fail(MCBS_EINVAL, "state buffer too small: need %zu bytes", rb * S.E);
     const mcbs_topo_header* th = b->topo->H();
-    HIP_TRY(hipSetDevice(b->cfg.device));
+    DeviceGuard guard(b->cfg.device);
+    HIP_TRY(guard.err);
     HIP_TRY(hipDeviceSynchronize());
     std::vector<uint8_t> host(b->arena_bytes);
     HIP_TRY(hipMemcpy(host.data(), b->arena, b->arena_bytes, hipMemcpyDeviceToHost));   // keeps init image, digest, episode

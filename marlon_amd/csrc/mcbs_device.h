@@ -151,10 +151,13 @@ struct StepCfg {        // the parts of mcbs_batch_cfg the kernels read
     uint64_t ere_lib_cols;   // columns that are library (global) vulnerabilities: present on every node, always
     const uint32_t* ere_lists;
     uint32_t off_service_cold, off_allowed_cold;   // (aliases of off_service / off_allowed, kept next to their only hot-path user)
-    // mcbs_rollout_random: the step kernel samples each step's action itself (written before every launch of that entry point)
-    uint32_t roll_mode;      // 0 off (actions are read), 1 uniform in the action space, 2 the sample_valid_action distribution
-    uint32_t roll_nmax, roll_cmax;
-    uint64_t roll_seed, roll_step0;
+};
+
+// mcbs_rollout_random: the looping step kernel samples each step's action itself; passed as a kernel argument of that variant only
+struct RollArgs {
+    uint32_t mode = 0;       // 0 off (actions are read), 1 uniform in the action space, 2 the sample_valid_action distribution
+    uint32_t nmax = 0, cmax = 0, pad = 0;
+    uint64_t seed = 0, step0 = 0;
 };
 
 struct StepIO {

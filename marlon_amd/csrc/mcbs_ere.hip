@@ -57,10 +57,12 @@ struct EreView {
             for (uint32_t i = 0; i < t.svc_cnt; ++i) {
                 const double w = SV()[t.svc_off + i].sla_weight;
                 total += w;
-                running += w * (double)((run >> i) & 1u);
+                running = __dadd_rn(running, __dmul_rn(w, (double)((run >> i) & 1u)));
             }
             total_nodes += t.sla_weight;
-            avail += ((1.0 + running) / (1.0 + total)) * t.sla_weight;
+            // product and sum rounded separately, as Python floats do (actions.py:743); a fused multiply-add rounds once and can
+            // differ in the last bit for non-dyadic weights (the Makefile also passes -ffp-contract=off)
+            avail = __dadd_rn(avail, __dmul_rn((1.0 + running) / (1.0 + total), t.sla_weight));
         }
         return avail / total_nodes;
     }

@@ -371,8 +371,10 @@ struct Lane {
 // PHASE 2: defender, goals, outputs, auto-reset (after the observation kernels ran).
 // WT: words per set held in registers (1, 2 or 4; >= NW, SW, TW).  TOPO_LDS: topology tables staged in LDS.
 // DEFK: MCBS_DEFENDER_* (none / in-env ScanAndReimage / external learned defender).
-template <int PHASE, int WTP, bool TOPO_LDS, int DEFK, bool MANY = false>
-__global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, const StepCfg* __restrict__ Cp, StepIO io) {
+// MANY: the in-kernel step loop of mcbs_step_many / mcbs_rollout_random (step_many_kernel below); `roll` = the random agent of
+// mcbs_rollout_random (mode 0: actions are read from io.actions).
+template <int PHASE, int WTP, bool TOPO_LDS, int DEFK, bool MANY>
+__device__ __forceinline__ void step_body(const DevState& S, const Topo& T, const StepCfg* __restrict__ Cp, const StepIO& io, const RollArgs& roll) {
     constexpr bool PK = WTP == 0;           // packed batch: the eight sets are 16-bit fields of one uint4 per env
     constexpr int WT = PK ? 1 : WTP;
     const StepCfg& C = *Cp;   // in device memory: fields are fetched by scalar loads where they are used, not all up front
@@ -417,9 +419,9 @@ __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, const Ste
     uint4 a03 = make_uint4(0, 0, 0, 0);
     uint32_t a4 = 0;
     uint4 dhead = make_uint4(0, 0, 0, 0), chead0 = dhead, chead1 = dhead;
-    if (MANY && C.roll_mode) {                          // on-device random agent: this step's action comes from the env's own state
+    if (MANY && roll.mode) {                            // on-device random agent: this step's action comes from the env's own state
         int32_t ra[5];
-        sample_action(S, T, C, ec, C.roll_mode == 2u, C.roll_seed, C.roll_step0 + it, C.roll_nmax, C.roll_cmax, ra);
+        sample_action(S, T, C, ec, roll.mode == 2u, roll.seed, roll.step0 + it, roll.nmax, roll.cmax, ra);
         a03 = make_uint4((uint32_t)ra[0], (uint32_t)ra[1], (uint32_t)ra[2], (uint32_t)ra[3]);
         a4 = (uint32_t)ra[4];
         if (io.actions && active) {
@@ -676,6 +678,20 @@ __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, const Ste
         o[7] = __builtin_amdgcn_s_memrealtime();
     }
 #endif
+}
+
+// One launch = one CyberBattleEnv.step of every env.  The argument list must stay below 256 bytes (mcbs_api.hip make_io): the random
+// agent's parameters therefore travel only with the looping variant below, which is launched once per K steps.
+template <int PHASE, int WTP, bool TOPO_LDS, int DEFK>
+__global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, const StepCfg* __restrict__ Cp, StepIO io) {
+    step_body<PHASE, WTP, TOPO_LDS, DEFK, false>(S, T, Cp, io, RollArgs{});
+}
+
+// mcbs_step_many / mcbs_rollout_random: io.n_steps consecutive steps in one launch; `roll` is a kernel ARGUMENT (nothing in device
+// memory is patched per call, so launches on different streams or inside a stream capture cannot see each other's mode).
+template <int WTP, bool TOPO_LDS, int DEFK>
+__global__ __launch_bounds__(256) void step_many_kernel(DevState S, Topo T, const StepCfg* __restrict__ Cp, StepIO io, RollArgs roll) {
+    step_body<0, WTP, TOPO_LDS, DEFK, true>(S, T, Cp, io, roll);
 }
 
 } // namespace mcbs
