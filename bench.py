@@ -3,7 +3,7 @@
 
 Metric (BASELINE.json): env-steps/sec at 65536 envs, CyberBattleChain-10; bit-exact vs CPU ref.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1: starts N ranks itself, see below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -14,20 +14,29 @@ steps (marlon's max_timesteps, attack_wrapper.py:38); actions are valid random a
 CyberBattleEnv.sample_valid_action, recorded by an untimed rollout of the same engine and replayed from an
 HBM ring (the replay is exact: attacker-only Chain has no randomness).  Weak scaling: every rank owns its own
 65 536 envs (global env ids rank*E ..), no collective on the data path; the only collectives are the timing
-barrier / MAX and an optional all_gather of episode returns after the timed region.
+barrier / MAX / gathers and an all_gather of episode returns after the timed region.
 
 The timed region replays the K steps from a hipGraph (launch-bound inner loop captured once), bracketed by
 barrier + synchronize on both sides.  The dominant kernel's average launch duration is measured in the same process
 with HIP events on the launch stream bracketing that timed region (/ K; a per-launch event-pair figure from an eager
-replay of the same K steps is printed beside it as an upper bound) and reported as a fraction of the HBM roofline;
-the CPU oracle (oracle/, a port of the reference's algorithm, NOT the product) is timed on one host core on a
-bounded sample of the same action ring, and its rewards are compared with the GPU's while at it.
+replay of the same K steps is printed beside it as an upper bound) and reported as a fraction of the HBM roofline.
+Beside the headline (never as `value`): `configs` — the step kernels of BASELINE.json's configs 3, 4 (one GPU's shard) and
+5 (one GPU's shard) timed the same way, with their roofline fraction from MEASURED HBM bytes (profiles/round2_step_*.json,
+tied to the kernel sources by a hash); `observe` — the observation tier; `cpu_baseline` — the CPU oracle (oracle/, a port of
+the reference's algorithm, NOT the product) timed on the host cores on a bounded sample of the same action ring, its rewards
+and termination flags compared with the GPU's, and the reference's own Python path as timed in the build container.
+
+`python bench.py --gpus N` invoked plainly (no RANK / WORLD_SIZE in the environment) starts the N ranks itself: before
+anything touches the GPU it runs `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...` on this same file as a
+child process, passes rank 0's JSON line through and exits with the child's code.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -38,21 +47,11 @@ if REPO not in sys.path:
 ENVS_PER_GPU = 65536
 B_STEP = 348            # algorithmic bytes per env-step, SURVEY.md section 8(d) (attacker-only tier)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+METRIC = "env-steps/sec at 65536 envs, CyberBattleChain-10; bit-exact vs CPU ref"
+HEADLINE_KERNEL = "mcbs::step_kernel<0, 0, true, 0>"
 
 
-def build_engine(rank: int, local_rank: int, n_envs: int, max_episode_steps: int):
-    from marlon_amd import engine, flatten
-    from marlon_amd._abi import EnvSpec
-    from marlon_amd.samples import chainpattern
-
-    topo = flatten.flatten(chainpattern.new_environment(10))
-    spec = EnvSpec(n_envs=n_envs, maximum_node_count=12, maximum_total_credentials=12,
-                   attacker_goal=dict(own_atleast_percent=1.0), auto_reset=True,
-                   max_episode_steps=max_episode_steps, seed=12345, env_id_base=rank * n_envs, device=local_rank)
-    return engine.BatchEngine(topo, spec, device=f"cuda:{local_rank}"), topo, spec
-
-
-def main() -> int:
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
@@ -60,61 +59,200 @@ def main() -> int:
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--max-episode-steps", type=int, default=2000)
     ap.add_argument("--cpu-envs", type=int, default=65536)
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU oracle sample: repeat the recorded steps until about this long (1 core; half of it on all cores)")
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of a hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse the "
-                    "multi-rank code path on a single-GPU box together with --single-device)")
-    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
-    args = ap.parse_args()
+    ap.add_argument("--no-extras", action="store_true", help="skip the `configs` and `observe` legs (they run at N = 1 only)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the timing collectives for N>1 (nccl = RCCL; gloo is the "
+                    "agreed fallback when RCCL cannot be brought up on every rank)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal on a one-GPU box: every rank uses cuda:0")
+    ap.add_argument("--rehearse", action="store_true", help="launcher / collective / JSON plumbing only, NO engine and no GPU (CPU-safe: "
+                    "tests/test_distributed_gloo.py); prints value null")
+    ap.add_argument("--master-port", type=int, default=0, help="self-launch only: rendezvous port (0 = pick a free one)")
+    return ap.parse_args(argv)
 
-    import numpy as np
+
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a child `torch.distributed.run` (never re-exec: this process
+    has not touched the GPU and will not), forward rank 0's JSON line, return the child's exit code."""
+    port = args.master_port or free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + [a for a in sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this pool
+    env["MCBS_BENCH_SELF_LAUNCHED"] = "1"
+    print(f"bench.py: starting {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr)
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line)
+    if proc.returncode != 0:
+        print(f"bench.py: a rank failed (torch.distributed.run exit code {proc.returncode})", file=sys.stderr)
+        return proc.returncode
+    return 0 if line is not None else 1
+
+
+def init_collectives(world: int, rank: int, local_rank: int, want: str, use_gpu: bool):
+    """Process group for the timing collectives.  The default group is always gloo (it cannot fail half-way); RCCL is brought up as
+    a second group inside a try, every rank reports whether its probe all-reduce went through, and the ranks AGREE (MIN over gloo)
+    before any of them uses it — a rank whose RCCL init failed can therefore not leave the others waiting at an RCCL barrier.
+    Returns (backend name, group or None, device for collective tensors)."""
+    import datetime
     import torch
     import torch.distributed as dist
+    if world == 1:
+        return "none", None, torch.device("cpu")
+    dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=300))
+    if want != "nccl" or not use_gpu:
+        return "gloo", None, torch.device("cpu")
+    ok, group = 1, None
+    try:
+        group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120))
+        probe = torch.ones(1, device=f"cuda:{local_rank}")
+        dist.all_reduce(probe, group=group)                 # communicators are created lazily: fail here, not in the timed region
+        torch.cuda.synchronize()
+        ok = int(probe.item() == world)
+    except Exception as exc:
+        print(f"bench.py rank {rank}: RCCL unavailable ({type(exc).__name__}: {exc})", file=sys.stderr)
+        ok = 0
+    flag = torch.tensor([ok], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)             # gloo: every rank takes the same decision
+    if int(flag.item()) == 1:
+        return "nccl", group, torch.device(f"cuda:{local_rank}")
+    if rank == 0:
+        print("bench.py: RCCL did not come up on every rank; timing collectives over gloo (the data path has no collective)", file=sys.stderr)
+    return "gloo", None, torch.device("cpu")
 
+
+def load_traffic(name: str, kernel_prefix: str):
+    """Measured HBM bytes per launch of one kernel from profiles/round2_<name>.json (tools/profile_all.sh + tools/pmc_summary.py).
+    Returns (bytes_per_launch or None, info dict).  A file taken on other kernel sources than the ones this tree builds is STALE:
+    its figure is not used."""
+    from tools import workloads as W
+    path = os.path.join(REPO, "profiles", f"round2_{name}.json")
+    info = {"file": os.path.relpath(path, REPO)}
+    if not os.path.exists(path):
+        info["status"] = "missing"
+        return None, info
+    try:
+        d = json.load(open(path))
+        k = next(k for k in d["kernels"] if k["kernel"].startswith(kernel_prefix) and k.get("hbm_bytes_per_launch") is not None)
+    except Exception as exc:
+        info["status"] = f"unreadable ({type(exc).__name__})"
+        return None, info
+    info.update(kernel=k["kernel"], rocprof_avg_us=k["avg_us"], rocprof_min_us=k["min_us"], calls=k["calls"],
+                csrc_sha256=d.get("csrc_sha256", "")[:16], git_head=d.get("git_head_when_collected", ""))
+    if d.get("csrc_sha256") != W.csrc_sha256():
+        info["status"] = "stale: the kernel sources changed since these counters were taken"
+        return None, info
+    info["status"] = "current"
+    return float(k["hbm_bytes_per_launch"]), info
+
+
+def reference_python_timing():
+    """The reference's own CPU path, timed in the build container (it cannot travel to the GPU box)."""
+    try:
+        d = json.load(open(os.path.join(REPO, "profiles", "reference_cpu_timing.json")))
+        one = next(r for r in d["rows"] if r["config"] == "chain10" and r["processes"] == 1)
+        many = next(r for r in d["rows"] if r["config"] == "chain10" and r["processes"] > 1)
+        return {"value": one["step_only_steps_per_s"], "unit": "env-steps/s", "cores": 1, "kind": "reference",
+                "all_cores": {"value": many["step_only_steps_per_s_sum"], "cores": many["processes"]},
+                "whole_loop_value": one["loop_steps_per_s"],
+                "host": "build container, 8 cores (NOT the GPU box: the reference cannot travel)", "source": "profiles/reference_cpu_timing.json",
+                "what": "unmodified CyberBattleEnv.step, Chain-10 bounds 12/12, attacker only, one env per process",
+                "note": d.get("note", "")}
+    except Exception as exc:
+        return {"value": None, "error": f"{type(exc).__name__}: {exc}"}
+
+
+def rehearse(args, world, rank, local_rank) -> int:
+    """No engine, no GPU: the launcher, the agreed-backend collectives and the JSON assembly with a stand-in timed region."""
+    import torch
+    import torch.distributed as dist
+    backend, group, coll_dev = init_collectives(world, rank, local_rank, args.backend, use_gpu=False)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    per_rank = [elapsed]
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        allt = [torch.empty_like(tt) for _ in range(world)]
+        dist.all_gather(allt, tt)
+        per_rank = [float(x.item()) for x in allt]
+        mine = torch.full((4,), float(rank), dtype=torch.float64)
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        assert [float(g[0]) for g in gathered] == [float(r) for r in range(world)]
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "value": None, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
+                          "data": "synthetic", "rehearsal": "launcher and collectives only: no engine, no GPU, nothing measured",
+                          "collective_backend": backend, "ranks_in_group": dist.get_world_size() if world > 1 else 1,
+                          "per_rank_ms": [x * 1e3 for x in per_rank],
+                          "self_launched": os.environ.get("MCBS_BENCH_SELF_LAUNCHED") == "1"}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+def main() -> int:
+    args = parse_args()
+    have_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not have_launcher:
+        return self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
-            return 2
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} ranks", file=sys.stderr)
+        return 2
+    if args.rehearse:
+        return rehearse(args, world, rank, local_rank)
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from tools import workloads as W
+
     if args.single_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    backend = args.backend
-    if world > 1:
-        if backend == "nccl":
-            try:
-                dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
-                probe = torch.zeros(1, device=f"cuda:{local_rank}")
-                dist.all_reduce(probe)                      # RCCL communicators are created lazily: fail here, not in the timed region
-                torch.cuda.synchronize()
-            except Exception as exc:                        # the data path has no collective: only the timing barrier / MAX need one,
-                print(f"bench.py: RCCL unavailable ({exc}); timing collectives over gloo", file=sys.stderr)   # so gloo is enough
-                if dist.is_initialized():
-                    dist.destroy_process_group()
-                backend = "gloo"
-                dist.init_process_group("gloo")
-        else:
-            dist.init_process_group(backend)
-    coll_dev = torch.device(f"cuda:{local_rank}") if backend == "nccl" else torch.device("cpu")
+    backend, group, coll_dev = init_collectives(world, rank, local_rank, args.backend, use_gpu=True)
 
     def barrier():
         if world > 1:
-            dist.barrier()
+            dist.barrier(group=group)
 
-    E, K, W = args.envs_per_gpu, args.steps, args.warmup
-    from marlon_amd._abi import EnvSpec  # noqa: F401
-    eng, topo, spec = build_engine(rank, local_rank, E, args.max_episode_steps)
+    E, K, Wm = args.envs_per_gpu, args.steps, args.warmup
+    eng, topo, spec, desc = W.make_engine("headline", n_envs=E, env_id_base=rank * E, device=f"cuda:{local_rank}",
+                                          max_episode_steps=args.max_episode_steps, seed=12345)
     dev = eng.device
 
     # ---- untimed: record W+K batches of valid random actions into an HBM ring, then rewind ----
-    ring = torch.empty((W + K, E, 5), dtype=torch.int32, device=dev)
-    for t in range(W + K):
+    ring = torch.empty((Wm + K, E, 5), dtype=torch.int32, device=dev)
+    for t in range(Wm + K):
         eng.sample_actions(True, seed=12345, step=t, out=ring[t])
         eng.step(ring[t], with_info=False)
     torch.cuda.synchronize()
-    eng.reset()          # back to the initial state: the replay below repeats the recorded trajectory exactly
+    eng.reset()          # back to the initial state: the replay below repeats the recorded trajectory exactly (attacker only: no draws)
     rewards = torch.empty((K, E), dtype=torch.float32, device=dev)
     dones = torch.empty((K, E), dtype=torch.uint8, device=dev)
     lib, h = eng.lib, eng._h
@@ -126,7 +264,7 @@ def main() -> int:
 
     # ---- warm-up (untimed) ----
     st = torch.cuda.current_stream().cuda_stream
-    for t in range(W):
+    for t in range(Wm):
         launch(t, t % K, st)
     torch.cuda.synchronize()
 
@@ -140,7 +278,7 @@ def main() -> int:
             with torch.cuda.graph(graph, stream=side):
                 s = torch.cuda.current_stream().cuda_stream
                 for t in range(K):
-                    launch(W + t, t, s)
+                    launch(Wm + t, t, s)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         # graph capture does not execute: state is still "after warm-up"
@@ -155,75 +293,79 @@ def main() -> int:
         graph.replay()
     else:
         for t in range(K):
-            launch(W + t, t, st)
+            launch(Wm + t, t, st)
     ev1.record()
     torch.cuda.synchronize()
     barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed_mine = time.perf_counter() - t0
     region_us = ev0.elapsed_time(ev1) * 1e3 / K          # device time per launch over the timed region, launch gaps included
+    elapsed, per_rank = elapsed_mine, [elapsed_mine]
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        tt = torch.tensor([elapsed_mine], dtype=torch.float64, device=coll_dev)
+        allt = [torch.empty_like(tt) for _ in range(world)]
+        dist.all_gather(allt, tt, group=group)
+        per_rank = [float(x.item()) for x in allt]
+        mx = tt.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
+        elapsed = float(mx.item())
 
     reward_sum_timed = rewards.double().sum(dim=0)          # per-env return over the K timed steps
-    n_done = int(dones.sum().item())
+    done_cnt_timed = dones.long().sum(dim=0)                # per-env `terminated` flags raised in the K timed steps
+    n_done = int(done_cnt_timed.sum().item())
 
     # ---- cross-check: one HIP event pair around EACH launch, same K steps, eager, from the same start state.  The pair
     # itself costs ~2 us per launch at this kernel size, so this figure is an upper bound; `kernel_us` (the roofline's
     # denominator) is the event-bracketed timed region / K, which is what rocprofv3's kernel trace agrees with ----
     eng.reset()
-    for t in range(W):
+    for t in range(Wm):
         launch(t, t % K, st)
     torch.cuda.synchronize()
     eng.timing_enable(True)
     for t in range(K):
-        launch(W + t, t, st)
+        launch(Wm + t, t, st)
     kernel_ms, launches = eng.timing_read()
     eng.timing_enable(False)
     pair_us = kernel_ms * 1e3 / max(1, launches)
     kernel_us = region_us
-    same = bool(torch.equal(rewards.double().sum(dim=0), reward_sum_timed))
+    same = bool(torch.equal(rewards.double().sum(dim=0), reward_sum_timed) and torch.equal(dones.long().sum(dim=0), done_cnt_timed))
 
     # ---- extra, NOT the headline: the same K recorded steps through mcbs_step_many (one launch, no per-step launch cost) ----
     eng.reset()
-    for t in range(W):
+    for t in range(Wm):
         launch(t, t % K, st)
     many_r = torch.empty((K, E), dtype=torch.float32, device=dev)
     many_d = torch.empty((K, E), dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
     m0, m1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     m0.record()
-    eng.step_many(ring[W:W + K], many_r, many_d)
+    eng.step_many(ring[Wm:Wm + K], many_r, many_d)
     m1.record()
     torch.cuda.synchronize()
     many_us = m0.elapsed_time(m1) * 1e3 / K
-    many_same = bool(torch.equal(many_r.double().sum(dim=0), reward_sum_timed))
+    many_same = bool(torch.equal(many_r.double().sum(dim=0), reward_sum_timed) and torch.equal(many_d.long().sum(dim=0), done_cnt_timed))
 
     # ---- optional logging collective (not on the data path): episode returns of every rank ----
     if world > 1:
         mine = reward_sum_timed.to(coll_dev)
         gathered = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(gathered, mine)
+        dist.all_gather(gathered, mine, group=group)
 
     result = None
+    parity_ok = same and many_same
     if rank == 0:
         bytes_per_launch = float(B_STEP) * E
         achieved = bytes_per_launch / (kernel_us * 1e-6) / 1e9
-        traffic = None
-        tf = os.path.join(REPO, "profiles", "traffic_step_kernel.json")
-        if os.path.exists(tf):
-            try:
-                traffic = json.load(open(tf)).get("bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic, tinfo = load_traffic("step_headline", "mcbs::step_kernel<0, 0, true, 0")
+        if traffic is not None and E != ENVS_PER_GPU:
+            traffic, tinfo["status"] = None, "not applicable: counters were taken at 65 536 envs per launch"
+        per_rank_value = [E * K / x for x in per_rank]
         result = {
-            "metric": "env-steps/sec at 65536 envs, CyberBattleChain-10; bit-exact vs CPU ref",
+            "metric": METRIC,
             "value": world * E * K / elapsed,
             "unit": "env-steps/s",
             "n_gpus": world,
             "steps": K,
-            "warmup": W,
+            "warmup": Wm,
             "ms_per_step": elapsed * 1e3 / K,
             "higher_is_better": True,
             "scaling": "weak",
@@ -234,54 +376,141 @@ def main() -> int:
                                    f"auto-reset, truncation at {args.max_episode_steps} steps",
                        "envs_per_gpu": E, "launch": "hipGraph replay" if graph is not None else "eager",
                        "episodes_ended_in_timed_region_rank0": n_done},
+            "collective_backend": backend, "ranks_in_group": world,
+            "per_rank_ms_per_step": [x * 1e3 / K for x in per_rank],
+            "n1_value_hint": sum(per_rank_value) / len(per_rank_value),     # what ONE GPU did in this run (mean over ranks): compare with the N = 1 line
+            "self_launched": os.environ.get("MCBS_BENCH_SELF_LAUNCHED") == "1",
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "mcbs::step_kernel<0, 0, true, 0, false>", "kernel_us": kernel_us, "launches_timed": K,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tinfo,
+                         "kernel": HEADLINE_KERNEL, "kernel_us": kernel_us, "launches_timed": K,
                          "kernel_us_event_pair_per_launch": pair_us,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "bytes_per_env_step": B_STEP,
-                         "replay_rewards_equal_timed_region": same},
+                         "frac_of_measured_traffic": None if traffic is None else traffic / (kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                         "replay_rewards_and_dones_equal_timed_region": same},
             # scripted-sequence entry point (no reference counterpart): K steps in ONE launch; reported beside, never as, `value`
-            "step_many": {"us_per_step": many_us, "env_steps_per_s_rank0": E / (many_us * 1e-6), "rewards_equal_timed_region": many_same},
+            "step_many": {"us_per_step": many_us, "env_steps_per_s_rank0": E / (many_us * 1e-6), "rewards_and_dones_equal_timed_region": many_same},
         }
-        if not args.no_cpu_baseline:
-            n = min(args.cpu_envs, E)
-            acts = ring[W:W + K, :n].cpu().numpy()
-            # the oracle starts from reset; the GPU's timed region started after W warm-up steps: feed it those too
-            warm = ring[:W, :n].cpu().numpy()
-            import numpy as _np
-            full = _np.concatenate([warm, acts], axis=0)
-            from oracle.oracle import Oracle
-            import copy
-            s2 = copy.copy(spec)
-            s2.n_envs = n
-            ref_sum = reward_sum_timed[:n].cpu().numpy()
-
-            def cpu_leg(threads: int):
-                orc = Oracle(topo, s2)
-                orc.run(full[:W], threads)                       # warm-up steps, untimed
-                t0 = time.perf_counter()
-                tot = orc.run(full[W:], threads)                 # K steps of every env inside C (env-major: cache-resident state)
-                dt = time.perf_counter() - t0
-                del orc
-                return dt, bool(_np.array_equal(tot, ref_sum))
-
-            dt, eq = cpu_leg(1)
-            result["cpu_baseline"] = {
-                "value": n * K / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
-                "sample": f"first {n} envs x {K} steps of the same action ring ({dt:.1f} s), scalar C oracle oracle/cbs_oracle.c, "
-                          f"K-step loop inside C",
-                "rewards_equal_gpu": eq,
-            }
-            cores = max(1, min(os.cpu_count() or 1, 64, n))
-            dt_all, eq_all = cpu_leg(cores)      # envs never interact: disjoint env ranges on all host cores
-            result["cpu_baseline"]["all_cores"] = {"value": n * K / dt_all, "cores": cores, "seconds": round(dt_all, 2),
-                                                   "rewards_equal_gpu": eq_all}
-        print(json.dumps(result))
+    ring_cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        n = min(args.cpu_envs, E)
+        ring_cpu = ring[:, :n].cpu().numpy()
+        ref_sum, ref_done = reward_sum_timed[:n].cpu().numpy(), done_cnt_timed[:n].cpu().numpy().astype(np.int32)
     eng.close()
+    del ring, rewards, dones, many_r, many_d, graph
+    torch.cuda.empty_cache()
+
+    # ---- beside the headline, N = 1 only: the other BASELINE.json configurations and the observation tier ----
+    if rank == 0 and world == 1 and not args.no_extras:
+        try:
+            result["configs"] = extras_configs(W)
+            result["observe"] = extras_observe(W)
+        except Exception as exc:      # the headline stands on its own; an extras failure is reported, not hidden
+            result["extras_error"] = f"{type(exc).__name__}: {exc}"
+            parity_ok = False
+
+    if rank == 0 and ring_cpu is not None:
+        from oracle.oracle import Oracle
+        import copy
+        n = ring_cpu.shape[1]
+        s2 = copy.copy(spec)
+        s2.n_envs = n
+
+        def cpu_leg(threads: int, budget_s: float):
+            # the oracle starts from reset like the GPU did: W warm-up steps (untimed), then the K timed ones; the whole pass is
+            # repeated from a fresh oracle until the time budget is used, every pass checked against the GPU's results
+            steps_done, dt, eq = 0, 0.0, True
+            while dt < budget_s:
+                orc = Oracle(topo, s2)
+                if Wm:
+                    orc.run(ring_cpu[:Wm], threads)
+                c0 = time.perf_counter()
+                tot, ended = orc.run(ring_cpu[Wm:], threads, count_terminated=True)
+                dt += time.perf_counter() - c0
+                steps_done += n * K
+                eq = eq and bool(np.array_equal(tot, ref_sum)) and bool(np.array_equal(ended, ref_done))
+                del orc
+            return steps_done / dt, dt, eq, steps_done
+
+        v1, dt1, eq1, sd1 = cpu_leg(1, args.cpu_seconds)
+        cores = max(1, min(os.cpu_count() or 1, 64, n))
+        va, dta, eqa, sda = cpu_leg(cores, args.cpu_seconds / 2)     # envs never interact: disjoint env ranges on all host cores
+        result["cpu_baseline"] = {
+            "value": v1, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": f"first {n} envs x {K} steps of the same action ring, repeated {sd1 // (n * K)}x from reset ({dt1:.1f} s of CPU work), "
+                      f"scalar C oracle oracle/cbs_oracle.c, K-step loop inside C (env-major: each env's state stays in cache)",
+            "rewards_and_dones_equal_gpu": eq1,
+            "all_cores": {"value": va, "cores": cores, "seconds": round(dta, 2), "rewards_and_dones_equal_gpu": eqa},
+            "reference_python": reference_python_timing(),
+        }
+        parity_ok = parity_ok and eq1 and eqa
+
+    if rank == 0:
+        result["parity_ok"] = bool(parity_ok)
+        if not parity_ok:
+            # "bit-exact vs CPU ref" is part of the metric: a run whose checks fail has no headline value
+            result["value_unverified"] = result["value"]
+            result["value"] = None
+        print(json.dumps(result))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    return 0
+    return 0 if parity_ok else 3
+
+
+def extras_configs(W):
+    """Step kernels of BASELINE.json configs 3-5 (per-GPU shard for the 8-GPU ones): hipGraph replay of recorded valid actions on a
+    fresh engine, HIP events on the launch stream; roofline fraction from the MEASURED HBM bytes of the same kernel (two --pmc passes,
+    profiles/round2_step_<config>.json) — SURVEY 8(d)'s N*64/scan_frequency defender term is not used: the bit-mask / ring state never
+    moves the per-node rows it charges."""
+    out = []
+    for name, K in (("config3", 300), ("config4", 300), ("config5", 300)):
+        ring = W.record_ring(name, K)
+        eng, topo, spec, desc = W.make_engine(name)
+        us, rewards, dones = W.graph_replay_us(eng, ring, K)
+        kern = "mcbs::step_kernel<0, "
+        traffic, tinfo = load_traffic(f"step_{name}", kern)
+        row = {"workload": f"{desc}, {eng.E} envs", "name": name, "envs": eng.E, "nodes": topo.n_nodes, "steps": K,
+               "us_per_step": us, "env_steps_per_s": eng.E / (us * 1e-6),
+               "reward_sum": float(rewards.double().sum()), "episodes_ended": int(dones.sum()),
+               "roofline": {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": traffic, "traffic_source": tinfo,
+                            "achieved": None if traffic is None else traffic / (us * 1e-6) / 1e9,
+                            "frac": None if traffic is None else traffic / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                            "bytes_per_env_step_measured": None if traffic is None else traffic / eng.E}}
+        out.append(row)
+        eng.close()
+        del ring, rewards, dones
+        import torch
+        torch.cuda.empty_cache()
+    return out
+
+
+def extras_observe(W):
+    """Observation tier (SURVEY 8(d) B_obs): the whole observation in the reference's dtypes / layout, one mcbs_observe per call."""
+    import torch
+    out = []
+    for name, label in (("headline", "all fields"), ("config3", "all fields")):
+        ring = W.record_ring(name, 40)
+        eng, topo, spec, desc = W.make_engine(name)
+        us, bpe, obs = W.observe_us(eng, ring, W.OBS_FIELDS, reps=20)
+        gbps = bpe * eng.E / (us * 1e-6) / 1e9
+        row = {"workload": f"{desc}, {eng.E} envs, {label} (int32 fields + three int8 action masks)", "name": name, "envs": eng.E,
+               "us_per_observe": us, "bytes_per_env": bpe, "GBps": gbps, "frac": gbps / HBM_PEAK_GBS, "bound": "hbm (writes)",
+               "env_observations_per_s": eng.E / (us * 1e-6)}
+        traffic, tinfo = load_traffic(f"obs_{name}", "mcbs::obs_small_kernel")
+        row["traffic"] = traffic
+        row["traffic_source"] = tinfo
+        out.append(row)
+        del obs
+        if name == "headline":      # the MaskablePPO path: small fields + the flat Discrete mask (connect | local | remote)
+            us2, bpe2, obs2 = W.observe_us(eng, ring, W.OBS_FIELDS[:5] + ["mask_discrete"], reps=20, advance=0)
+            g2 = bpe2 * eng.E / (us2 * 1e-6) / 1e9
+            out.append({"workload": f"{desc}, {eng.E} envs, small fields + mask_discrete (MaskablePPO path)", "name": "headline_discrete",
+                        "envs": eng.E, "us_per_observe": us2, "bytes_per_env": bpe2, "GBps": g2, "frac": g2 / HBM_PEAK_GBS, "bound": "hbm (writes)"})
+            del obs2
+        eng.close()
+        del ring
+        torch.cuda.empty_cache()
+    return out
 
 
 if __name__ == "__main__":

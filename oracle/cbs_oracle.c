@@ -809,19 +809,22 @@ int cbo_step(void* h, const int32_t* actions, double* reward, uint8_t* terminate
 }
 
 /* Timing helper for bench.py's cpu_baseline leg: K consecutive steps of envs [env_lo, env_hi), env-major (every env's
- * state stays cache-resident for its K steps: the CPU's best case), rewards summed per env.  actions [K, E, 5].
+ * state stays cache-resident for its K steps: the CPU's best case), rewards summed and `terminated` flags counted per env.
+ * actions [K, E, 5].
  * Envs never interact, so disjoint ranges may run on different threads of the same handle. */
-int cbo_run(void* h, const int32_t* actions, int K, int env_lo, int env_hi, double* reward_sum) {
+int cbo_run(void* h, const int32_t* actions, int K, int env_lo, int env_hi, double* reward_sum, int32_t* episodes_ended) {
     oracle* o = (oracle*)h; int errors = 0;
     for (int i = env_lo; i < env_hi; ++i) {
-        double acc = 0.0;
+        double acc = 0.0; int32_t ended = 0;
         for (int t = 0; t < K; ++t) {
             ostep r;
             if (step_env(o, &o->env[i], o->cfg.env_id_base + (uint64_t)i, actions + ((size_t)t * o->n_envs + (size_t)i) * 5,
                          NULL, 0, NULL, &r) != 0) errors++;
             acc += r.reward;
+            ended += r.terminated != 0;          /* (truncations are not counted: bench.py compares the `terminated` flags) */
         }
         reward_sum[i] = acc;
+        if (episodes_ended) episodes_ended[i] = ended;
     }
     return errors;
 }

@@ -45,7 +45,7 @@ def _load():
     lib.cbo_step.restype = C.c_int
     lib.cbo_step.argtypes = [C.c_void_p] + [C.c_void_p] * 9 + [C.c_int, C.c_void_p]
     lib.cbo_run.restype = C.c_int
-    lib.cbo_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    lib.cbo_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     for name, n in (("cbo_exploit_local", 4), ("cbo_exploit_remote", 5), ("cbo_connect", 6)):
         getattr(lib, name).argtypes = [C.c_void_p] + [C.c_int] * (n - 1) + [C.POINTER(C.c_double)]
     lib.cbo_check_prerequisites.restype = C.c_int
@@ -145,24 +145,26 @@ class Oracle:
             C.byref(b) if b is not None else None)
         return out
 
-    def run(self, actions: np.ndarray, threads: int = 1) -> np.ndarray:
+    def run(self, actions: np.ndarray, threads: int = 1, count_terminated: bool = False):
         """K steps of every env (actions [K, E, 5]), env-major inside C, split over `threads` host threads; returns the
-        per-env reward sum.  Timing helper for bench.py's cpu_baseline leg (envs are independent)."""
+        per-env reward sum (and, with count_terminated, the per-env number of `terminated` flags raised).  Timing helper for
+        bench.py's cpu_baseline leg (envs are independent)."""
         a = np.ascontiguousarray(actions, dtype=np.int32).reshape(-1, self.E, 5)
         K = a.shape[0]
         acc = np.zeros(self.E, np.float64)
+        ended = np.zeros(self.E, np.int32)
         cuts = [self.E * i // threads for i in range(threads + 1)]
         if threads == 1:
-            self.lib.cbo_run(self.h, a.ctypes.data, K, 0, self.E, acc.ctypes.data)
-            return acc
-        import threading
-        ths = [threading.Thread(target=self.lib.cbo_run, args=(self.h, a.ctypes.data, K, cuts[i], cuts[i + 1], acc.ctypes.data))
-               for i in range(threads)]
-        for th in ths:
-            th.start()
-        for th in ths:
-            th.join()
-        return acc
+            self.lib.cbo_run(self.h, a.ctypes.data, K, 0, self.E, acc.ctypes.data, ended.ctypes.data)
+        else:
+            import threading
+            ths = [threading.Thread(target=self.lib.cbo_run, args=(self.h, a.ctypes.data, K, cuts[i], cuts[i + 1], acc.ctypes.data, ended.ctypes.data))
+                   for i in range(threads)]
+            for th in ths:
+                th.start()
+            for th in ths:
+                th.join()
+        return (acc, ended) if count_terminated else acc
 
     # -- actuator level (AgentActions without the gym env) --
     def exploit_local(self, node: int, local_idx: int, env: int = 0):

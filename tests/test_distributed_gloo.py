@@ -83,3 +83,43 @@ def test_two_shards_equal_one_batch_under_gloo():
     np.testing.assert_array_equal(gathered, full)        # sharding is invisible in the results
     assert elapsed == 0.002                              # MAX over ranks
     assert full.sum() > 0
+
+
+def _run_bench(argv, env_extra=None, timeout=240):
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + argv, env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_self_launches_ranks_when_invoked_plainly():
+    """`python bench.py --gpus 2` with no launcher in the environment (how the driver invokes N = 1) must start the two ranks
+    itself and print rank 0's JSON line.  --rehearse keeps it CPU-safe: launcher, backend agreement, barrier / MAX / gathers and
+    the JSON assembly run for real, the engine does not (value null)."""
+    p, line = _run_bench(["--gpus", "2", "--steps", "7", "--warmup", "2", "--rehearse"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert line is not None and line["n_gpus"] == 2 and line["ranks_in_group"] == 2 and line["steps"] == 7 and line["warmup"] == 2
+    assert line["self_launched"] is True and line["collective_backend"] == "gloo" and line["value"] is None
+    assert len(line["per_rank_ms"]) == 2 and line["scaling"] == "weak"
+    assert line["metric"].startswith("env-steps/sec at 65536 envs, CyberBattleChain-10")
+
+
+def test_bench_under_an_external_launcher_and_rank_failure_is_an_error():
+    """The driver's own multi-GPU form (`python -m torch.distributed.run ... bench.py --gpus N`) does not self-launch again; a
+    world size that contradicts --gpus makes every rank exit non-zero, and the launcher reports it."""
+    import subprocess
+    env = dict(os.environ)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "2", "--rehearse", "--steps", "3"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and '"self_launched": false' in lines[0]
+    cmd[cmd.index("--gpus") + 1] = "4"                      # 2 ranks started, 4 announced
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert p.returncode != 0

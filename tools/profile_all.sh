@@ -1,0 +1,26 @@
+#!/bin/bash
+# rocprofv3 evidence for the numbers bench.py prints (run on the MI355X box from the repo root):
+#   tools/profile_all.sh [tag] [workload ...]
+# For every workload three separate runs — `--kernel-trace --stats`, `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE` (the two counters
+# cannot share a pass on gfx950 and --pmc is never combined with other tracing) — into gpurun_out/prof_<tag>/<workload>/{stats,fetch,write}.
+# Summarise afterwards (in the build container, where .git is) with tools/pmc_summary.py workload ... -> profiles/.
+set -o pipefail
+export TMPDIR=/tmp
+tag=${1:-r2}
+shift || true
+if [ $# -gt 0 ]; then wl=("$@"); else
+wl=(step:headline step:config3 step:config4 step:config5 obs:headline obs:config3 obs:config4 discrete:headline); fi
+root=$(pwd)/gpurun_out/prof_${tag}
+mkdir -p "$root"
+for w in "${wl[@]}"; do
+    d="$root/${w/:/_}"
+    mkdir -p "$d"
+    k=200; case "$w" in obs:config4) k=5;; obs:*|discrete:*|logits:*) k=20;; esac
+    echo "== $w (K=$k)"
+    rocprofv3 --kernel-trace --stats --output-format csv -d "$d/stats" -o run -- python3 tools/profile_run.py "$w" $k > "$d/stats.log" 2>&1 || { echo "stats run failed for $w"; tail -5 "$d/stats.log"; exit 1; }
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$d/fetch" -o run -- python3 tools/profile_run.py "$w" $k > "$d/fetch.log" 2>&1 || { echo "fetch run failed for $w"; tail -5 "$d/fetch.log"; exit 1; }
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$d/write" -o run -- python3 tools/profile_run.py "$w" $k > "$d/write.log" 2>&1 || { echo "write run failed for $w"; tail -5 "$d/write.log"; exit 1; }
+    # summarise on the spot and drop the bulky raw CSVs (gpurun_out is capped at 64 MiB)
+    python3 tools/pmc_summary.py workload "$d" || exit 1
+done
+du -sh "$root"

@@ -1,0 +1,135 @@
+"""BASELINE.json's workloads as the benchmark and the profiling tools run them (shared by bench.py, tools/profile_run.py and
+tools/bench_configs.py so that a rocprofv3 summary under profiles/ and a bench.py line describe the same launches).
+
+A workload = (topology, per-GPU env count, EnvSpec keywords).  Names:
+    headline  Chain-10, 65 536 envs, attacker only                                   (BASELINE.json metric, configs[1] shape)
+    config2   Chain-10, 4 096 envs, attacker only
+    config3   ToyCtf, 16 384 envs, ScanAndReimage(0.6, 2, 5), SLA 0.80, own_atleast 6
+    config4   Chain-100 (N 102, C 102), 8 192 envs = one GPU's shard of 65 536, ScanAndReimage(0.6, 2, 5)
+    config5   Random-256 (this build's config-5 generator, seed 0), 16 384 envs = one GPU's shard of 131 072, ScanAndReimage(0.5, 4, 4)
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import subprocess
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+OBS_FIELDS = ["scalars", "leaked_credentials", "credential_cache_matrix", "discovered_nodes_properties", "nodes_privilegelevel",
+              "mask_local", "mask_remote", "mask_connect"]
+
+
+def workload(name: str):
+    from marlon_amd import flatten, model
+    from marlon_amd.samples import chainpattern, random_net, toy_ctf
+    if name in ("headline", "config2"):
+        return (flatten.flatten(chainpattern.new_environment(10)), 65536 if name == "headline" else 4096,
+                dict(maximum_node_count=12, maximum_total_credentials=12, attacker_goal=dict(own_atleast_percent=1.0)),
+                "CyberBattleChain size=10, attacker only")
+    if name == "config3":
+        return (flatten.flatten(toy_ctf.new_environment()), 16384,
+                dict(maximum_node_count=12, maximum_total_credentials=10, attacker_goal=dict(own_atleast=6, own_atleast_percent=1.0),
+                     maintain_sla=0.8, defender=("scan_and_reimage", 0.6, 2, 5)),
+                "CyberBattleToyCtf, attacker + ScanAndReimage(0.6, 2, 5), SLA 0.80")
+    if name == "config4":
+        return (flatten.flatten(chainpattern.new_environment(100)), 8192,
+                dict(maximum_node_count=102, maximum_total_credentials=102, attacker_goal=dict(own_atleast_percent=1.0),
+                     defender=("scan_and_reimage", 0.6, 2, 5)),
+                "CyberBattleChain size=100, attacker + ScanAndReimage(0.6, 2, 5); one GPU's shard (1/8) of 65 536 envs")
+    if name == "config5":
+        topo = flatten.flatten(random_net.build(model, 256, 0))
+        return (topo, 16384,
+                dict(maximum_node_count=256, maximum_total_credentials=256, maximum_discoverable_credentials_per_action=8,
+                     attacker_goal=dict(own_atleast_percent=1.0), maintain_sla=0.5, defender=("scan_and_reimage", 0.5, 4, 4)),
+                "Random 256-node topology, attacker + ScanAndReimage(0.5, 4, 4); one GPU's shard (1/8) of 131 072 envs")
+    raise KeyError(name)
+
+
+def make_engine(name: str, n_envs: int = 0, env_id_base: int = 0, device: str = "cuda:0", max_episode_steps: int = 2000, seed: int = 7):
+    from marlon_amd import engine
+    from marlon_amd._abi import EnvSpec
+    topo, E, kw, desc = workload(name)
+    E = n_envs or E
+    spec = EnvSpec(n_envs=E, auto_reset=True, max_episode_steps=max_episode_steps, seed=seed, env_id_base=env_id_base, **kw)
+    return engine.BatchEngine(topo, spec, device=device), topo, spec, desc
+
+
+def record_ring(name: str, K: int, n_envs: int = 0, env_id_base: int = 0, device: str = "cuda:0", seed: int = 7):
+    """K batches of valid random actions (the distribution of sample_valid_action) recorded by an untimed rollout of a
+    THROW-AWAY engine of the same workload: a fresh engine with the same seed then replays exactly the recorded trajectory,
+    defender draws included (Philox is keyed by (seed, global env id, episode, step); a reset would advance the episode)."""
+    import torch
+    eng, _, _, _ = make_engine(name, n_envs, env_id_base, device, seed=seed)
+    ring = torch.empty((K, eng.E, 5), dtype=torch.int32, device=eng.device)
+    for t in range(K):
+        eng.sample_actions(True, seed=seed, step=t, out=ring[t])
+        eng.step(ring[t], with_info=False)
+    torch.cuda.synchronize()
+    eng.close()
+    return ring
+
+
+def graph_replay_us(eng, ring, K: int):
+    """us per mcbs_step launch: the K recorded steps captured into one hipGraph and replayed ONCE on a fresh engine, HIP events
+    on the launch stream around the replay.  Returns (us_per_step, rewards[K, E], dones[K, E])."""
+    import torch
+    rewards = torch.empty((K, eng.E), dtype=torch.float32, device=eng.device)
+    dones = torch.empty((K, eng.E), dtype=torch.uint8, device=eng.device)
+    lib, h = eng.lib, eng._h
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            s = torch.cuda.current_stream().cuda_stream
+            for t in range(K):
+                if lib.mcbs_step(h, ring[t].data_ptr(), rewards[t].data_ptr(), dones[t].data_ptr(), None, s) != 0:
+                    raise RuntimeError(lib.mcbs_last_error().decode())
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / K, rewards, dones
+
+
+def observe_us(eng, ring, fields, reps: int = 20, advance: int = 40):
+    """us per mcbs_observe of `fields` (int8 masks and int32 fields in the reference's layout) on a batch that has been advanced by
+    `advance` recorded steps, HIP events on the launch stream.  Returns (us, bytes per env, obs dict)."""
+    import torch
+    obs = eng.alloc_obs(fields)
+    bytes_per_env = sum(v[0].numel() * v.element_size() for v in obs.values())
+    for t in range(min(advance, ring.shape[0])):
+        eng.step(ring[t], with_info=False)
+    for _ in range(3):
+        eng.observe(obs)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        eng.observe(obs)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps, bytes_per_env, obs
+
+
+def csrc_sha256() -> str:
+    """Hash of every source the native library is built from: ties a counter file under profiles/ to the kernels it was taken on
+    (the GPU box has no .git, so a commit id is not available there)."""
+    h = hashlib.sha256()
+    d = os.path.join(REPO, "marlon_amd", "csrc")
+    for f in sorted(os.listdir(d)) + ["../../include/mcbs.h"]:
+        if f.endswith((".hip", ".h")):
+            with open(os.path.join(d, f), "rb") as fh:
+                h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()
+
+
+def git_head() -> str:
+    try:
+        return subprocess.run(["git", "-C", REPO, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, check=True).stdout.strip()
+    except Exception:
+        return ""
