@@ -1,0 +1,144 @@
+"""The SB3 VecEnv calling surface (marlon_amd/vecenv.py) driven with the exact call sequence of the reference's rollout step
+(marlon/baseline_models/multiagent/baseline_marlon_agent.py:100-167: get_action_masks(env) -> env_method("action_masks"),
+env.step(actions) -> 4-tuple, _update_info_buffer(infos)) and checked against the traces captured from the reference's own
+AttackerEnvWrapper / MaskedDiscreteAttackerWrapper (tests/golden/wrap_*.npz): rewards, dones, TimeLimit.truncated, terminal
+observations, reset observations, action masks, and VecMonitor's episode statistics."""
+import json
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from tests import parity
+from tests.test_gpu_facades import FLAT, WRAP
+
+pytestmark = pytest.mark.gpu
+
+
+def _flat_equal(obs, i, z, prefix, t, ctx):
+    from marlon_amd.cyberbattle_env import SCALAR_KEYS
+    ref = (lambda k: z[prefix + k]) if t is None else (lambda k: z[prefix + k][t])
+    assert [int(np.asarray(obs[k]).reshape(-1)[i] if np.asarray(obs[k]).ndim == 1 else np.asarray(obs[k])[i]) for k in SCALAR_KEYS] == ref("scalars").tolist(), ctx + " scalars"
+    for k in FLAT:
+        np.testing.assert_array_equal(np.asarray(obs[k][i]).reshape(-1), np.asarray(ref(k)).reshape(-1), err_msg=f"{ctx} {k}")
+
+
+def _make(name, n_envs=1):
+    from marlon_amd import cyberbattle_env as ce
+    from marlon_amd._abi import RNG_TAPE
+    from marlon_amd.vecenv import MarlonVecEnv
+    from marlon_amd.wrappers import AttackerVecEnv
+    z = np.load(os.path.join(parity.GOLDEN, name + ".npz"))
+    sj = json.loads(bytes(z["spec_json"]).decode())
+    topo = parity.topology_for("toyctf" if "toyctf" in name else "chain10")
+    d = sj["defender"]
+    att = AttackerVecEnv(topo, n_envs, maximum_node_count=sj["maximum_node_count"], maximum_total_credentials=sj["maximum_total_credentials"],
+                         attacker_goal=ce.AttackerGoal(**sj["attacker_goal"]), defender_constraint=ce.DefenderConstraint(sj["maintain_sla"]),
+                         defender_agent=None if d is None else ce.ScanAndReimageCompromisedMachines(d[1], d[2], d[3]),
+                         max_timesteps=sj["max_timesteps"], discrete=sj["discrete"], rng_kind=RNG_TAPE)
+    return z, sj, MarlonVecEnv(att)
+
+
+@pytest.mark.parametrize("name", WRAP)
+def test_vecenv_call_sequence_reproduces_reference_wrapper_traces(name):
+    z, sj, env = _make(name)
+    assert env.num_envs == 1
+    last_obs = env.reset()                                                     # OnPolicyAlgorithm._setup_learn: self._last_obs = env.reset()
+    _flat_equal(last_obs, 0, z, "first_", None, name + " reset")
+    ep_info_buffer, resets, ret, length, prev_mask_ok = [], 0, 0.0, 0, False
+    for t in range(len(z["reward"])):
+        ctx = f"{name} step {t}"
+        action_masks = np.stack(env.env_method("action_masks"))                # sb3_contrib.common.maskable.utils.get_action_masks
+        assert action_masks.shape == (1, env.venv.discrete_n) and action_masks.dtype == np.bool_
+        if prev_mask_ok:                                                       # the masks the policy sees now = the ones recorded after step t-1
+            assert int(action_masks.sum()) == z["mask_sum"][t - 1] and zlib.crc32(action_masks[0].astype(np.int8).tobytes()) == z["mask_crc"][t - 1], ctx + " masks"
+        if z["tape"].size:
+            env.venv.engine.set_draw_tape(z["tape"][t:t + 1])
+        clipped_actions = np.asarray(z["action"][t]).reshape((1,) if sj["discrete"] else (1, 10))
+        step_result = env.step(clipped_actions)
+        assert len(step_result) == 4                                            # VecEnv API: (obs, rewards, dones, infos)
+        new_obs, rewards, dones, infos = step_result
+        assert isinstance(infos, list) and len(infos) == 1 and isinstance(infos[0], dict)
+        assert rewards.dtype == np.float32 and dones.dtype == np.bool_ and rewards.shape == (1,) and dones.shape == (1,)
+        assert float(rewards[0]) == z["reward"][t], f"{ctx} reward {rewards[0]} != {z['reward'][t]}"
+        term, trunc = bool(z["terminated"][t]), bool(z["truncated"][t])
+        assert bool(dones[0]) == (term or trunc), ctx + " done"
+        assert infos[0]["TimeLimit.truncated"] == (trunc and not term), ctx + " TimeLimit.truncated"
+        assert infos[0]["invalid_action"] == bool(z["invalid"][t]) and infos[0]["cyber_step_executed"] == (not z["invalid"][t]), ctx
+        ret += float(z["reward"][t])
+        length += 1
+        for info in infos:                                                      # BaseAlgorithm._update_info_buffer
+            maybe_ep_info = info.get("episode")
+            if maybe_ep_info is not None:
+                ep_info_buffer.append(maybe_ep_info)
+        if dones[0]:
+            assert z["was_reset"][t]
+            _flat_equal({k: v[np.newaxis] for k, v in infos[0]["terminal_observation"].items()}, 0, z, "", t, ctx + " terminal observation")
+            _flat_equal(new_obs, 0, z, "after_reset_", resets, ctx + " observation after the auto-reset")
+            assert ep_info_buffer[-1]["r"] == ret and ep_info_buffer[-1]["l"] == length and ep_info_buffer[-1]["t"] >= 0.0, ctx + " episode statistics"
+            ret, length, resets = 0.0, 0, resets + 1
+            prev_mask_ok = False
+        else:
+            assert "terminal_observation" not in infos[0] and "episode" not in infos[0]
+            _flat_equal(new_obs, 0, z, "", t, ctx)
+            prev_mask_ok = True
+        last_obs = new_obs
+    assert len(ep_info_buffer) == int(z["was_reset"].sum()) > 0
+    assert env.get_attr("max_timesteps") == [sj["max_timesteps"]] and env.env_is_wrapped(object) == [False]
+    assert env.get_attr("timesteps") == [length]
+    env.close()
+
+
+def test_vecenv_batch_matches_the_wrapper_it_adapts():
+    """2 048 envs, Discrete actions sampled from the masks obtained through env_method: the adapter's 4-tuple, per-env infos, episode
+    statistics and terminal observations against the same AttackerVecEnv stepped directly, and tensors instead of arrays with
+    numpy_outputs=False."""
+    import torch
+    from marlon_amd import cyberbattle_env as ce
+    from marlon_amd.samples import chainpattern
+    from marlon_amd.vecenv import MarlonVecEnv
+    from marlon_amd.wrappers import AttackerVecEnv
+    E = 2048
+
+    def mk():
+        return AttackerVecEnv(chainpattern.new_environment(4), E, maximum_node_count=6, maximum_total_credentials=6,
+                              attacker_goal=ce.AttackerGoal(own_atleast_percent=1.0), max_timesteps=30, discrete=True)
+    a, raw = MarlonVecEnv(mk()), mk()
+    dev_env = MarlonVecEnv(mk(), numpy_outputs=False)
+    obs = a.reset()
+    raw.reset()
+    dev_env.reset()
+    g = torch.Generator(device="cpu").manual_seed(5)
+    ret, length, episodes = np.zeros(E), np.zeros(E, np.int64), 0
+    for t in range(90):
+        masks = np.stack(a.env_method("action_masks"))
+        assert masks.shape == (E, a.venv.discrete_n) and np.array_equal(masks, a.action_masks())
+        scores = torch.rand(masks.shape, generator=g).numpy()
+        actions = np.where(masks, scores, -1.0).argmax(axis=1)
+        if t % 7 == 3:
+            actions[::5] = a.venv.discrete_n - 1                     # an undiscovered node index: intercepted, reward -1, env not stepped
+        new_obs, rewards, dones, infos = a.step(actions)
+        o2, r2, term2, trunc2, info2 = raw.step(actions)
+        o3, r3, d3, i3 = dev_env.step(torch.as_tensor(actions, device=dev_env.venv.engine.device))
+        assert isinstance(r3, torch.Tensor) and r3.is_cuda and isinstance(o3["connect"], torch.Tensor)
+        np.testing.assert_array_equal(rewards, r2.cpu().numpy())
+        np.testing.assert_array_equal(r3.cpu().numpy(), rewards)
+        np.testing.assert_array_equal(dones, ((term2 | trunc2) != 0).cpu().numpy())
+        np.testing.assert_array_equal(d3.cpu().numpy(), dones)
+        for k in new_obs:
+            np.testing.assert_array_equal(new_obs[k], o2[k].cpu().numpy(), err_msg=f"step {t} obs {k}")
+        ret += rewards
+        length += 1
+        for i in np.flatnonzero(dones):
+            assert infos[i]["episode"]["r"] == ret[i] and infos[i]["episode"]["l"] == length[i]
+            assert infos[i]["TimeLimit.truncated"] == bool(trunc2[i] and not term2[i])
+            for k in ("connect", "discovered_nodes_properties", "nodes_privilegelevel"):
+                np.testing.assert_array_equal(infos[i]["terminal_observation"][k], raw.terminal_observation[k][i].cpu().numpy())
+            episodes += 1
+        for i in np.flatnonzero(~dones)[:50]:
+            assert "episode" not in infos[i] and "terminal_observation" not in infos[i]
+        ret[dones], length[dones] = 0.0, 0
+    assert episodes >= E                                                 # every env ended (win or truncation at 30) at least once
+    assert a.get_attr("timesteps", indices=[0, 5]) == [int(length[0]), int(length[5])]
+    a.close(); raw.close(); dev_env.close()

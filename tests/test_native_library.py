@@ -76,3 +76,11 @@ def test_engine_refuses_to_run_without_gpu():
     topo = flatten.flatten(chainpattern.new_environment(4))
     with pytest.raises(engine.McbsError, match="no CPU fallback"):
         engine.BatchEngine(topo, EnvSpec(n_envs=4, maximum_node_count=6, maximum_total_credentials=6))
+
+
+def test_vecenv_surface_is_importable_without_gpu_or_sb3():
+    """The SB3-VecEnv adapter names what baseline_marlon_agent.py:100-167 calls; importing it needs neither a GPU, SB3 nor gymnasium."""
+    from marlon_amd import vecenv
+    for cls in (vecenv.MarlonVecEnv, vecenv.DefenderVecEnvAdapter):
+        for m in ("reset", "step_async", "step_wait", "step", "env_method", "get_attr", "env_is_wrapped", "seed", "close"):
+            assert callable(getattr(cls, m)), (cls.__name__, m)
