@@ -226,3 +226,99 @@ def main_defender():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "defender":
         main_defender()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Two-agent EPISODES in the call order of marl_algorithm.run_episode (marlon/baseline_models/multiagent/marl_algorithm.py:176-250;
+# that module itself cannot be imported: it needs Stable-Baselines3).  Each agent's `.env` there is a DummyVecEnv, which resets a
+# wrapper inside step_wait as soon as it reports done; that auto-reset is what makes the defender's step AFTER an attacker `done`
+# return `-last attacker reward` with truncated=True (reset_request protocol: attack_wrapper.py:433-435, defend_wrapper.py:269-271,
+# 479-482).  The loop below issues exactly those calls on the reference's own wrapper objects (defender re-bound to the live
+# environment after every reset, as above) and records what they return.
+def run_two_agent_episodes(name, make_cyber_env, spec, n_episodes, seed, max_timesteps, max_steps):
+    from marlon.baseline_models.env_wrappers.defend_wrapper import DefenderEnvWrapper
+    from marlon.baseline_models.env_wrappers.environment_event_source import EnvironmentEventSource
+    rng = np.random.Generator(np.random.PCG64(seed))
+    cyber = make_cyber_env()
+    events = EnvironmentEventSource()
+    aw = AttackerEnvWrapper(cyber, event_source=events, max_timesteps=max_timesteps, invalid_action_reward_modifier=-1)
+    dw = DefenderEnvWrapper(cyber, attacker_reward_store=aw, event_source=events, defender=True, max_timesteps=max_timesteps,
+                            invalid_action_reward=-1, reset_on_constraint_broken=True, loss_reward=-5000.0)
+
+    def rebind():
+        dw._actuator = cyber._defender_actuator
+        dw.defender._actuator = cyber._defender_actuator
+        dw.defender._environment = cyber.environment
+
+    def attacker_env_reset():      # DummyVecEnv.reset / the auto-reset inside step_wait
+        aw.reset()
+        rebind()
+
+    def defender_env_reset():
+        dw.reset()
+        rebind()
+        dw._prev_network_availability = float(dw._actuator.network_availability)
+        dw.last_availability = dw._prev_network_availability
+
+    nvec_a, nvec_d = np.asarray(aw.action_space.nvec), np.asarray(dw.action_space.nvec)
+    nodes = list(cyber.environment.network.nodes)
+    rec = {k: [] for k in ["episode", "a_action", "a_reward", "a_done", "d_action", "d_reward", "d_done", "d_terminated", "d_truncated"]}
+    ends = []
+    for ep in range(n_episodes):
+        attacker_env_reset()                     # run_episode: attacker_agent.env.reset()
+        dw.on_reset(0)                           #              defender_agent.wrapper.on_reset(0)
+        defender_env_reset()                     #              defender_agent.env.reset()
+        aw._last_transformed_observation = aw.transform_observation(cyber.reset()[0])   # (the attacker's cached observation of the twice-reset env)
+        rebind()
+        n_steps, reason = 0, "max_steps"
+        while n_steps < max_steps:
+            a = (rng.random(10) * nvec_a).astype(np.int64)
+            nd = len(cyber._CyberBattleEnv__discovered_nodes)
+            if rng.random() < 0.85:
+                for i in (1, 3, 4, 6, 7):
+                    a[i] = rng.integers(0, nd)
+                a[9] = rng.integers(0, max(1, len(cyber._CyberBattleEnv__credential_cache)))
+            _, r1, term1, trunc1, _ = aw.step(a)
+            dones1 = bool(term1 or trunc1)
+            if dones1:
+                attacker_env_reset()             # DummyVecEnv auto-reset: notifies the defender (reset_request, last reward)
+            d = (rng.random(12) * nvec_d).astype(np.int64)
+            if rng.random() < 0.3:
+                owned = [i for i, n in enumerate(nodes) if cyber.environment.get_node(n).agent_installed]
+                d[0] = 0
+                d[1] = int(rng.choice(owned)) if owned and rng.random() < 0.7 else d[1]
+            _, r2, term2, trunc2, _ = dw.step(d)
+            dones2 = bool(term2 or trunc2)
+            if dones2:
+                defender_env_reset()
+            rec["episode"].append(ep); rec["a_action"].append(a); rec["a_reward"].append(float(r1)); rec["a_done"].append(int(dones1))
+            rec["d_action"].append(d); rec["d_reward"].append(float(r2)); rec["d_done"].append(int(dones2))
+            rec["d_terminated"].append(int(bool(term2))); rec["d_truncated"].append(int(bool(trunc2)))
+            if dones1 or dones2:
+                reason = ("attacker" if dones1 else "") + ("+" if dones1 and dones2 else "") + ("defender" if dones2 else "")
+                break
+            n_steps += 1
+        ends.append(reason)
+    out = {k: np.asarray(v) for k, v in rec.items()}
+    out["spec_json"] = np.frombuffer(json.dumps(dict(spec, max_timesteps=max_timesteps, max_steps=max_steps, ends=ends)).encode(), dtype=np.uint8)
+    path = os.path.join(G.GOLDEN, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name:28s} episodes={n_episodes} steps={len(out['a_reward'])} ends={ {e: ends.count(e) for e in set(ends)} } "
+          f"a_reward={out['a_reward'].sum():.1f} d_reward={out['d_reward'].sum():.1f} size={os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def main_episodes():
+    AG, DC = ref.env.AttackerGoal, ref.env.DefenderConstraint
+    sp = dict(maximum_node_count=12, maximum_total_credentials=10, maximum_discoverable_credentials_per_action=5,
+              attacker_goal=dict(reward=0.0, low_availability=1.0, own_atleast=6, own_atleast_percent=1.0),
+              winning_reward=5000.0, losing_reward=-5000.0, maintain_sla=0.60, defender=["external"])
+
+    def toyctf_marl():
+        return ref.CyberBattleToyCtf(attacker_goal=AG(own_atleast=6), defender_constraint=DC(maintain_sla=0.60), losing_reward=-5000.0,
+                                     maximum_node_count=12, maximum_total_credentials=10, throws_on_invalid_actions=False)
+    run_two_agent_episodes("wrap_episode_toyctf_s73", toyctf_marl, sp, 14, 73, 40, 200)
+    run_two_agent_episodes("wrap_episode_toyctf_s74", toyctf_marl, sp, 10, 74, 300, 25)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "episodes":
+    main_episodes()

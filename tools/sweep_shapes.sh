@@ -4,7 +4,5 @@ set -o pipefail
 wl=${@:-config3 config4 config5}
 for sw in "" "MCBS_NO_LDS_TOPO=1" "MCBS_STEP_BLOCK=64" "MCBS_STEP_BLOCK=128" "MCBS_STEP_BLOCK=256"; do
     echo "== switches: ${sw:-none}"
-    env $sw python3 tools/bench_configs.py 300 $wl 2>&1 | grep '^{' | python3 -c 'import sys,json
-for l in sys.stdin:
-    d=json.loads(l); print(f"   {d[\"workload\"]:10s} {d[\"envs\"]:6d} envs  {d[\"us_per_step\"]:7.2f} us/step  reward_sum {d[\"reward_sum\"]:.0f}")'
+    env $sw python3 tools/bench_configs.py 300 $wl 2>&1 | grep '^{' | cut -c1-150
 done
