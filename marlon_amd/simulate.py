@@ -1,18 +1,30 @@
-"""Batched episode driver: the counterpart of `marlon.simulate.simulate` -> `marl_algorithm.run_episode`
+"""Batched episode drivers: the counterpart of `marlon.simulate.simulate` -> `marl_algorithm.run_episode`
 (marlon/simulate.py:14-35, marlon/baseline_models/multiagent/marl_algorithm.py:144-252) for the step engine.
 
-The reference loop is `attacker.predict -> attacker.env.step -> [defender acts] -> record` until done or
-`max_steps`, one env at a time, returning plotly frames.  Here the same loop runs for `n_envs` environments at once
-on the device and returns per-env reward traces; the in-env defender (ScanAndReimage) acts inside the step kernel.
-Policies are callables `policy(env: AttackerVecEnv) -> actions` (device tensor); `random_policy` is the counterpart
-of RandomMarlonAgent / `_step_random_attacker` (marl_algorithm_multi.py:59-76): uniformly random VALID actions.
-Rendering (plotly graphs, simulation.py) is out of scope.
+`run_episode` is the reference loop for a whole batch: per step the attacker predicts and steps, THEN the defender predicts
+and steps (marl_algorithm.py:197-240), an env's episode stops as soon as either side reports done (:242-245) or after
+`max_steps` loop iterations (:197), and what comes back are the two reward traces.  One episode per env; envs that have
+finished are parked (their rows of the traces stay zero).  Rendering (`generate_graph_json`, plotly) is out of scope.
+
+The reference's agents step through a DummyVecEnv, which resets a wrapper as soon as it reports done.  That is visible in
+one place: when the ATTACKER ends the episode, its auto-reset notifies the defender wrapper (reset_request, attack_wrapper.py:433-435
+-> defend_wrapper.py:479-482), and the defender's step that the loop still takes returns `-1 * last attacker reward` with
+truncated=True (defend_wrapper.py:269-271), whatever its action.  `run_episode` returns exactly that value for such envs
+(tests/golden/wrap_episode_*.npz, captured from the reference's wrappers in this call order, pin it).
+
+Policies are callables `policy(env) -> actions` (device tensor or array): `attacker_policy(att: AttackerVecEnv)` gives
+MultiDiscrete rows [E,10] or Discrete indices [E]; `defender_policy(dfd: DefenderVecEnv)` gives [E,12] rows.
+`random_policy` is the counterpart of RandomMarlonAgent / `_step_random_attacker` (marl_algorithm_multi.py:59-76):
+uniformly random VALID actions.
+
+`run_episodes` keeps stepping with auto-reset for a fixed number of wrapper steps (throughput-style evaluation of an
+attacker); `run_random_agents` is the CyberBattleEnv-level random baseline, entirely on the device.
 """
 from __future__ import annotations
 
 from typing import Callable, Dict, Optional
 
-from .wrappers import AttackerVecEnv
+from .wrappers import AttackerVecEnv, DefenderVecEnv
 
 
 def random_policy(seed: int = 0) -> Callable[[AttackerVecEnv], object]:
@@ -30,10 +42,82 @@ def random_policy(seed: int = 0) -> Callable[[AttackerVecEnv], object]:
     return policy
 
 
-def run_episodes(env: AttackerVecEnv, policy: Optional[Callable] = None, max_steps: int = 2000) -> Dict[str, object]:
-    """Step every env of `env` (created with discrete=True for `random_policy`) for `max_steps` wrapper steps.
+def random_defender_policy(seed: int = 0) -> Callable[[DefenderVecEnv], object]:
+    """Uniform over the defender's MultiDiscrete space [5, N, N, 6, 2, N, 6, 2, N, 3, N, 3] (defend_wrapper.py:162-195)."""
+    state = {"gen": None}
+
+    def policy(dfd: DefenderVecEnv):
+        t = dfd.torch
+        dev = dfd.engine.device
+        if state["gen"] is None:
+            state["gen"] = t.Generator(device=dev)
+            state["gen"].manual_seed(seed)
+        nvec = t.as_tensor(dfd.nvec, device=dev, dtype=t.float64)
+        return (t.rand((dfd.num_envs, 12), generator=state["gen"], device=dev, dtype=t.float64) * nvec).long()
+    return policy
+
+
+def run_episode(att: AttackerVecEnv, dfd: Optional[DefenderVecEnv] = None, attacker_policy: Optional[Callable] = None,
+                defender_policy: Optional[Callable] = None, max_steps: int = 2000) -> Dict[str, object]:
+    """marl_algorithm.run_episode for every env of the batch `att` (and of `dfd`, which shares it).  `att` must have been created
+    with auto_reset=False: the episode boundary is this loop's business, as in the reference where run_episode stops at the first done.
+
+    Returns device tensors: `attacker_rewards` [T, E] float64 and `defender_rewards` [T, E] float64 (rows past an env's last step are
+    zero; `defender_rewards` is None without a defender), `lengths` [E] = entries of the reference's reward lists for that env,
+    `attacker_done` / `defender_done` [E] = which side ended it (both False: max_steps reached), and T = loop iterations taken."""
+    if att.auto_reset:
+        raise ValueError("run_episode needs an AttackerVecEnv created with auto_reset=False (one episode per env, ended by this loop)")
+    t = att.torch
+    dev = att.engine.device
+    E = att.num_envs
+    attacker_policy = attacker_policy or random_policy()
+    if dfd is not None and defender_policy is None:
+        defender_policy = random_defender_policy()
+    # attacker_agent.env.reset(); defender_agent.wrapper.on_reset(0); defender_agent.env.reset()   (marl_algorithm.py:176-181)
+    att.reset()
+    if dfd is not None:
+        dfd.reset()
+    a_rew, d_rew = [], []
+    alive = t.ones(E, dtype=t.bool, device=dev)
+    lengths = t.zeros(E, dtype=t.int64, device=dev)
+    a_done = t.zeros(E, dtype=t.bool, device=dev)
+    d_done = t.zeros(E, dtype=t.bool, device=dev)
+    n_steps = 0
+    while n_steps < max_steps:
+        actions1 = attacker_policy(att)
+        _, r1, term1, trunc1, _ = att.step(actions1)
+        dones1 = ((term1 | trunc1) != 0) & alive
+        r1 = t.where(alive, r1.double(), t.zeros((), dtype=t.float64, device=dev))
+        a_rew.append(r1)
+        dones2 = t.zeros_like(dones1)
+        if dfd is not None:
+            actions2 = t.as_tensor(defender_policy(dfd), device=dev).long().clone()
+            # envs whose episode is over — earlier, or just now on the attacker's side — take no defender turn on the device:
+            # for the latter the reference's defender steps a freshly re-initialised env and its result is discarded in favour of
+            # -1 * last attacker reward, truncated (defend_wrapper.py:269-271)
+            actions2[~alive | dones1, 0] = -2
+            _, r2, term2, trunc2, _ = dfd.step(actions2)
+            stepped = alive & ~dones1
+            dones2 = (((term2 | trunc2) != 0) & stepped) | dones1
+            r2 = t.where(stepped, r2, t.where(dones1, -r1, t.zeros((), dtype=t.float64, device=dev)))
+            d_rew.append(r2)
+        lengths += alive
+        ended = dones1 | dones2
+        a_done |= dones1
+        d_done |= dones2 & alive
+        alive = alive & ~ended
+        n_steps += 1
+        if not bool(alive.any()):                      # every env's episode is over (one host sync per step; the policies are host-driven anyway)
+            break
+    out = dict(attacker_rewards=t.stack(a_rew), defender_rewards=t.stack(d_rew) if dfd is not None else None, lengths=lengths,
+               attacker_done=a_done, defender_done=d_done, steps=n_steps)
+    return out
+
+
+def run_episodes(env: AttackerVecEnv, policy: Optional[Callable] = None, max_steps: int = 2000, record_actions: bool = False) -> Dict[str, object]:
+    """Step every env of `env` (created with discrete=True for `random_policy`, auto_reset=True) for `max_steps` wrapper steps.
     Returns device tensors: `rewards` [max_steps, E], `dones` [max_steps, E], `episodes` [E] finished episode counts,
-    `returns` [E] sum of rewards of finished episodes."""
+    `returns` [E] sum of rewards of finished episodes (and `actions` [max_steps, E, ...] with record_actions)."""
     t = env.torch
     policy = policy or random_policy()
     E = env.num_envs
@@ -41,15 +125,22 @@ def run_episodes(env: AttackerVecEnv, policy: Optional[Callable] = None, max_ste
     dones = t.zeros((max_steps, E), dtype=t.uint8, device=env.engine.device)
     episodes = t.zeros(E, dtype=t.int64, device=env.engine.device)
     returns = t.zeros(E, dtype=t.float64, device=env.engine.device)
+    acts = []
     env.reset()
     for s in range(max_steps):
-        _, r, term, trunc, info = env.step(policy(env))
+        a = policy(env)
+        if record_actions:
+            acts.append(t.as_tensor(a, device=env.engine.device).clone())
+        _, r, term, trunc, info = env.step(a)
         d = (term | trunc) != 0
         rewards[s] = r
         dones[s] = d
         episodes += d
         returns += t.where(d, info["episode_return"], t.zeros_like(info["episode_return"]))
-    return dict(rewards=rewards, dones=dones, episodes=episodes, returns=returns)
+    out = dict(rewards=rewards, dones=dones, episodes=episodes, returns=returns)
+    if record_actions:
+        out["actions"] = t.stack(acts)
+    return out
 
 
 def run_random_agents(engine, n_steps: int, valid: bool = True, seed: int = 0, chunk: int = 256) -> Dict[str, object]:

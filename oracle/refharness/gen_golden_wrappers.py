@@ -122,7 +122,7 @@ def main():
     run("wrap_chain10_discrete_s64", chain10, sp_c, 300, 64, True, 100, 0)
 
 
-if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "defender"):
+if __name__ == "__main__" and len(sys.argv) == 1:
     main()
 
 
@@ -235,7 +235,7 @@ if __name__ == "__main__":
 # return `-last attacker reward` with truncated=True (reset_request protocol: attack_wrapper.py:433-435, defend_wrapper.py:269-271,
 # 479-482).  The loop below issues exactly those calls on the reference's own wrapper objects (defender re-bound to the live
 # environment after every reset, as above) and records what they return.
-def run_two_agent_episodes(name, make_cyber_env, spec, n_episodes, seed, max_timesteps, max_steps):
+def run_two_agent_episodes(name, make_cyber_env, spec, n_episodes, seed, max_timesteps, max_steps, p_in_range=0.85):
     from marlon.baseline_models.env_wrappers.defend_wrapper import DefenderEnvWrapper
     from marlon.baseline_models.env_wrappers.environment_event_source import EnvironmentEventSource
     rng = np.random.Generator(np.random.PCG64(seed))
@@ -274,7 +274,7 @@ def run_two_agent_episodes(name, make_cyber_env, spec, n_episodes, seed, max_tim
         while n_steps < max_steps:
             a = (rng.random(10) * nvec_a).astype(np.int64)
             nd = len(cyber._CyberBattleEnv__discovered_nodes)
-            if rng.random() < 0.85:
+            if rng.random() < p_in_range:
                 for i in (1, 3, 4, 6, 7):
                     a[i] = rng.integers(0, nd)
                 a[9] = rng.integers(0, max(1, len(cyber._CyberBattleEnv__credential_cache)))
@@ -318,6 +318,9 @@ def main_episodes():
                                      maximum_node_count=12, maximum_total_credentials=10, throws_on_invalid_actions=False)
     run_two_agent_episodes("wrap_episode_toyctf_s73", toyctf_marl, sp, 14, 73, 40, 200)
     run_two_agent_episodes("wrap_episode_toyctf_s74", toyctf_marl, sp, 10, 74, 300, 25)
+    # short episodes, half of the attacker's actions out of range: the attacker's LAST reward is often -1, which the defender's final
+    # step must return negated (reset_request)
+    run_two_agent_episodes("wrap_episode_toyctf_s75", toyctf_marl, sp, 30, 75, 12, 100, p_in_range=0.5)
 
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "episodes":

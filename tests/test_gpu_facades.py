@@ -227,23 +227,6 @@ def test_attacker_vec_env_batch_against_oracle():
     env.close()
 
 
-def test_run_episodes_random_policy_finishes_chain4():
-    """Episode driver (marlon.simulate counterpart): masked-random attackers own the whole Chain-4 network."""
-    from marlon_amd import cyberbattle_env as ce
-    from marlon_amd.samples import chainpattern
-    from marlon_amd.simulate import random_policy, run_episodes
-    from marlon_amd.wrappers import AttackerVecEnv
-    env = AttackerVecEnv(chainpattern.new_environment(4), 512, maximum_node_count=6, maximum_total_credentials=6,
-                         attacker_goal=ce.AttackerGoal(own_atleast_percent=1.0), max_timesteps=400, discrete=True)
-    out = run_episodes(env, random_policy(seed=3), max_steps=400)
-    ep = out["episodes"].cpu().numpy()
-    assert (ep >= 1).all()                                        # every env ended at least one episode (win or truncation at 400)
-    r = out["rewards"].cpu().numpy()
-    assert r.min() >= 0.0 and r.sum() > 0                         # masked actions are never intercepted (no -1 modifier)
-    assert out["returns"].cpu().numpy().min() >= 0.0
-    env.close()
-
-
 # ---------------------------------------------------------------- learned defender (SURVEY.md section 8f-1)
 DEF_KEYS = ["infected_nodes", "incoming_firewall_status", "outgoing_firewall_status", "services_status"]
 
