@@ -347,6 +347,18 @@ int  mcbs_sample_actions(mcbs_batch*, int32_t valid, uint64_t seed, uint64_t ste
 int  mcbs_decode_attacker_actions(mcbs_batch*, const int64_t* multidiscrete, const int64_t* discrete,
                                   int32_t* actions_out, uint8_t* invalid_out, void* stream);
 
+/* ---- on-device action mask -> logits (what MaskablePPO does with action_masks(), train_marl_multi.py:259-293) ----
+ * logits: device [E, row_stride] float32 (MCBS_LOGITS_F32) or bfloat16 (MCBS_LOGITS_BF16), row e = the Discrete action scores of env e in
+ * MaskedDiscreteAttackerWrapper's order (action_masking.py:96-142: connect, local, remote; mcbs_discrete_action_count entries).
+ * In place: logits[e, a] = mask(e, a) ? logits[e, a] : fill, where mask is EXACTLY the mask_discrete the last observation call on this
+ * batch (mcbs_step_observe / mcbs_observe / mcbs_observe_masked / mcbs_action_mask) wrote or would have written — it is rebuilt from the
+ * per-env digest that call left (owned-source bits, discovered-node and cached-credential counts), so the N*N*P*C-byte mask itself need
+ * not be requested from the observation at all.  Not available for MCBS_DEFENDER_RANDOM_EVENTS batches (MCBS_ESTATE). */
+#define MCBS_LOGITS_F32  0
+#define MCBS_LOGITS_BF16 1
+uint64_t mcbs_discrete_action_count(const mcbs_batch*);
+int  mcbs_mask_logits(mcbs_batch*, void* logits, int32_t dtype, size_t row_stride, float fill, void* stream);
+
 /* ---- learned defender: marlon/baseline_models/env_wrappers/defend_wrapper.py:197-327,329-412,492-534
  * and marlon/defender_agents/defender.py:31-107, for batches created with MCBS_DEFENDER_EXTERNAL ---- */
 typedef struct mcbs_defender_obs {   /* DefenderEnvWrapper.observe: four MultiBinary fields, int8, network node order */

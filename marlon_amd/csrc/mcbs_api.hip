@@ -15,6 +15,7 @@
 #include "mcbs_obs.hip"
 #include "mcbs_aux.hip"
 #include "mcbs_defend.hip"
+#include "mcbs_logits.hip"
 
 using namespace mcbs;
 
@@ -46,6 +47,7 @@ static int fail(int code, const char* fmt, ...) {
         if (_e != hipSuccess) return fail(MCBS_EHIP, "%s failed: %s", #expr, hipGetErrorString(_e));      \
     } while (0)
 
+static FastDiv fast_div_host(uint32_t d);
 struct HotLayout { uint32_t node, desc, payload, auth, auth_words, triple, avail, fwlist, bytes; };
 
 struct mcbs_topology {
@@ -441,6 +443,12 @@ extern "C" int mcbs_batch_create(const mcbs_topology* topo, const mcbs_batch_cfg
     C.hot_node = topo->hot.node; C.hot_desc = topo->hot.desc; C.hot_payload = topo->hot.payload; C.hot_auth = topo->hot.auth;
     memcpy(C.rule_port, h->rule_port, 8); C.n_services = h->n_services; C.n_fw_lists = h->n_fw_lists; C.hot_fwlist = topo->hot.fwlist;
     C.auth_words = topo->hot.auth_words; C.hot_triple = topo->hot.triple; C.hot_avail = topo->hot.avail; C.hot_bytes = topo->hot.bytes;
+    C.avail_uniform = h->avail_any_order ? 1u : 0u;
+    C.avail_term0 = ns[0].avail_term;
+    for (uint32_t n = 0; n < N; ++n) {
+        if (ns[n].flags & MCBS_NODE_REIMAGABLE) C.reimagable[n >> 6] |= 1ull << (n & 63u);
+        if (ns[n].avail_term != ns[0].avail_term) C.avail_uniform = 0u;
+    }
 
     e = hipMalloc(&b->C_dev, sizeof(StepCfg));
     if (e == hipSuccess) e = hipMemcpy(b->C_dev, &b->C, sizeof(StepCfg), hipMemcpyHostToDevice);
@@ -535,9 +543,11 @@ static void launch_step_v(mcbs_batch* b, const StepIO& io, hipStream_t st, const
         if constexpr (MANY) hipLaunchKernelGGL((step_many_kernel<WT, true, DEF>), dim3((E + block - 1) / block), dim3(block), shm, st, b->S, b->T, b->C_dev, io, roll);
         else hipLaunchKernelGGL((step_kernel<PHASE, WT, true, DEF>), dim3((E + block - 1) / block), dim3(block), shm, st, b->S, b->T, b->C_dev, io);
     } else {
-        const uint32_t shm = b->S.wide ? 128u * b->S.TW * 8u : 0u;
-        if constexpr (MANY) hipLaunchKernelGGL((step_many_kernel<WT, false, DEF>), dim3((E + 127) / 128), dim3(128), shm, st, b->S, b->T, b->C_dev, io, roll);
-        else hipLaunchKernelGGL((step_kernel<PHASE, WT, false, DEF>), dim3((E + 127) / 128), dim3(128), shm, st, b->S, b->T, b->C_dev, io);
+        uint32_t block = 128u;
+        if (b->step_block_override) block = b->step_block_override;
+        const uint32_t shm = b->S.wide ? block * b->S.TW * 8u : 0u;
+        if constexpr (MANY) hipLaunchKernelGGL((step_many_kernel<WT, false, DEF>), dim3((E + block - 1) / block), dim3(block), shm, st, b->S, b->T, b->C_dev, io, roll);
+        else hipLaunchKernelGGL((step_kernel<PHASE, WT, false, DEF>), dim3((E + block - 1) / block), dim3(block), shm, st, b->S, b->T, b->C_dev, io);
     }
 }
 
@@ -671,15 +681,7 @@ static int launch_region(mcbs_batch* b, int8_t* dst, size_t env_stride, size_t r
         }
     }
     if (W == 16 && REGION != 2 && RL >= 16u && len < (1ull << 31) && !b->slow_masks) {
-        auto fd = [](uint32_t d) {   // n / d = (t + ((n - t) >> sh1)) >> sh2 with t = mulhi(n, mul)
-            uint32_t l = 0;
-            while ((1ull << l) < d) ++l;
-            FastDiv f;
-            f.mul = (uint32_t)(((1ull << 32) * ((1ull << l) - d)) / d + 1ull);
-            f.sh1 = l < 1u ? l : 1u;
-            f.sh2 = l > 0u ? l - 1u : 0u;
-            return f;
-        };
+        auto fd = [](uint32_t d) { return fast_div_host(d); };
         const uint32_t flat = chunks < 256 && (uint64_t)chunks * b->S.E < (1ull << 31) ? 1u : 0u;
         uint32_t gx = (uint32_t)((chunks + 1023) / 1024 < 8 ? (chunks + 1023) / 1024 : 8);
         uint32_t gy = 4096u / gx;
@@ -787,6 +789,54 @@ extern "C" int mcbs_decode_attacker_actions(mcbs_batch* b, const int64_t* multid
     hipLaunchKernelGGL(decode_kernel, dim3((b->S.E + 255) / 256), dim3(256), 0, (hipStream_t)stream, b->S, b->C_dev,
                        b->cfg.maximum_node_count, b->cfg.maximum_total_credentials, multidiscrete, discrete, actions_out, invalid_out);
     return launch_ok("decode");
+}
+
+// ------------------------------------------------------------------ action mask -> logits
+static FastDiv fast_div_host(uint32_t d) {   // n / d = (t + ((n - t) >> sh1)) >> sh2 with t = mulhi(n, mul)
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;
+    FastDiv f;
+    f.mul = (uint32_t)(((1ull << 32) * ((1ull << l) - d)) / d + 1ull);
+    f.sh1 = l < 1u ? l : 1u;
+    f.sh2 = l > 0u ? l - 1u : 0u;
+    return f;
+}
+
+extern "C" uint64_t mcbs_discrete_action_count(const mcbs_batch* b) {
+    if (!b) return 0;
+    const uint64_t N = b->cfg.maximum_node_count, C = b->cfg.maximum_total_credentials;
+    return N * N * b->C.P * C + N * b->C.L + N * N * b->C.R;
+}
+
+extern "C" int mcbs_mask_logits(mcbs_batch* b, void* logits, int32_t dtype, size_t row_stride, float fill, void* stream) {
+    if (!b || !logits) return fail(MCBS_EINVAL, "null argument");
+    if (dtype != MCBS_LOGITS_F32 && dtype != MCBS_LOGITS_BF16) return fail(MCBS_EINVAL, "logits dtype must be MCBS_LOGITS_F32 or MCBS_LOGITS_BF16");
+    if (b->cfg.defender_kind == MCBS_DEFENDER_RANDOM_EVENTS)
+        return fail(MCBS_ESTATE, "mcbs_mask_logits: under ExternalRandomEvents a node's local-vulnerability mask changes with the defender's "
+                                 "edits and is not part of the observation digest; use the materialised mask (mcbs_observe)");
+    const uint64_t A64 = mcbs_discrete_action_count(b);
+    if (A64 >= (1ull << 31)) return fail(MCBS_ELIMIT, "Discrete action space too large for one launch");
+    if (row_stride < A64) return fail(MCBS_EINVAL, "row_stride %zu is shorter than the %llu Discrete actions", row_stride, (unsigned long long)A64);
+    LogitsGeom G;
+    G.N = b->cfg.maximum_node_count; G.C = b->cfg.maximum_total_credentials; G.L = b->C.L; G.R = b->C.R; G.RL = b->C.P * G.C;
+    G.M = G.N * G.N * G.RL; G.ML = G.N * G.L; G.A = (uint32_t)A64;
+    G.dRL = fast_div_host(G.RL); G.dC = fast_div_host(G.C); G.dN = fast_div_host(G.N); G.dL = fast_div_host(G.L); G.dR = fast_div_host(G.R);
+    constexpr int U = 4;
+    const dim3 grid((G.A + 256u * 4u * U - 1u) / (256u * 4u * U), b->S.E), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t esz = dtype == MCBS_LOGITS_F32 ? 4 : 2;
+    const bool vec = row_stride % 4 == 0 && reinterpret_cast<uintptr_t>(logits) % (4 * esz) == 0;
+    if (dtype == MCBS_LOGITS_F32) {
+        if (vec) hipLaunchKernelGGL((mask_logits_kernel<float, U, true>), grid, block, 0, st, b->S, b->T, b->C_dev, b->digest, static_cast<float*>(logits), row_stride, fill, G);
+        else hipLaunchKernelGGL((mask_logits_kernel<float, U, false>), grid, block, 0, st, b->S, b->T, b->C_dev, b->digest, static_cast<float*>(logits), row_stride, fill, G);
+    } else {
+        uint32_t bits;                                   // float -> bfloat16, round to nearest even
+        memcpy(&bits, &fill, 4);
+        const uint16_t f16 = (bits & 0x7FFFFFFFu) > 0x7F800000u ? (uint16_t)((bits >> 16) | 0x40u) : (uint16_t)((bits + 0x7FFFu + ((bits >> 16) & 1u)) >> 16);
+        if (vec) hipLaunchKernelGGL((mask_logits_kernel<uint16_t, U, true>), grid, block, 0, st, b->S, b->T, b->C_dev, b->digest, static_cast<uint16_t*>(logits), row_stride, f16, G);
+        else hipLaunchKernelGGL((mask_logits_kernel<uint16_t, U, false>), grid, block, 0, st, b->S, b->T, b->C_dev, b->digest, static_cast<uint16_t*>(logits), row_stride, f16, G);
+    }
+    return launch_ok("mask logits");
 }
 
 // ------------------------------------------------------------------ learned defender

@@ -151,6 +151,12 @@ struct StepCfg {        // the parts of mcbs_batch_cfg the kernels read
     uint64_t ere_lib_cols;   // columns that are library (global) vulnerabilities: present on every node, always
     const uint32_t* ere_lists;
     uint32_t off_service_cold, off_allowed_cold;   // (aliases of off_service / off_allowed, kept next to their only hot-path user)
+    // defender look-ups that would otherwise be table reads AFTER the step's stores (a load behind a store waits for its write
+    // acknowledgement): which nodes may be re-imaged, as set words read through the scalar cache, and the availability term when every
+    // node has the same one (all reference samples: 1.0) and sums are exact in any order
+    uint64_t reimagable[4];
+    double   avail_term0;
+    uint32_t avail_uniform, pad_u;
 };
 
 // mcbs_rollout_random: the looping step kernel samples each step's action itself; passed as a kernel argument of that variant only

@@ -163,7 +163,9 @@ struct Lane {
     //            `port` / `triple` = connect arguments (0 for exploits).  Every index is valid for every lane.
     // WIDE_OK = false: the batch cannot have a wide cached-triple set (packed layout); compiles its handling out.
     // DK: the batch's defender kind; MCBS_DEFENDER_RANDOM_EVENTS consults the env's own vulnerability / service / firewall state
-    template <bool WIDE_OK, int DK>
+    // GLOBAL_TB: the hot image is read from global memory (not staged in LDS): every table read must then be ISSUED before the step's
+    // first store — a load behind a store waits for the store's write acknowledgement — so the leak payload is fetched up front
+    template <bool WIDE_OK, int DK, bool GLOBAL_TB>
     __device__ __forceinline__ void act(bool X, double raw_nx, int kind, uint32_t src, uint32_t tgt, uint32_t col, uint32_t port, uint32_t triple) {
         const bool k2 = kind == 2;
         // ---- look-ups of both flavours (LDS) ----
@@ -262,8 +264,16 @@ struct Lane {
         const bool stage = wide && cnt != 0u && creds;
         if (stage)
             for (uint32_t w = 0; w < S.TW; ++w) wide_lds[w * wide_stride] = S.cach[(size_t)w * S.E + e];
-        for (uint32_t i = 0; i < cnt; ++i) {
-            const uint2 p = pl[i];                       // {node | cred << 16, triple | port << 16}
+        constexpr uint32_t PF = 8;                       // payload entries fetched before the first store (longer lists: the tail loop loads)
+        uint2 pre[PF];
+        if (GLOBAL_TB) {
+#pragma unroll
+            for (uint32_t i = 0; i < PF; ++i) {
+                pre[i] = make_uint2(0u, 0u);
+                if (__ballot(i < cnt)) pre[i] = pl[i < cnt ? i : 0u];     // wave-uniform skip; the loads of one wave go out back to back
+            }
+        }
+        auto leak = [&](const uint2 p) {                 // one LeakedCredentials / LeakedNodesId entry {node | cred << 16, triple | port << 16}
             const uint32_t pn = p.x & 0xFFFFu, pc = p.x >> 16, pt = p.y & 0xFFFFu;
             // appends go to the slot past the list's end whether or not the element is new (the lists have one slack slot):
             // the count only advances for a new element, so a stale write is overwritten or never read
@@ -283,6 +293,16 @@ struct Lane {
 #pragma unroll
             for (int w = 0; w < WT; ++w) { m[M_DISC][w] |= b0[w]; m[M_GATH][w] |= b1[w]; m[M_CACH][w] |= b2[w]; }
             n_disc += new_n; nn += new_n; nc += new_g; n_creds += new_c; ncache += new_c;
+        };
+        if (GLOBAL_TB) {
+#pragma unroll
+            for (uint32_t i = 0; i < PF; ++i) {
+                if (!__ballot(i < cnt)) break;
+                if (i < cnt) leak(pre[i]);
+            }
+            for (uint32_t i = PF; i < cnt; ++i) leak(pl[i]);
+        } else {
+            for (uint32_t i = 0; i < cnt; ++i) leak(pl[i]);
         }
         if (stage)
             for (uint32_t w = 0; w < S.TW; ++w) S.cach[(size_t)w * S.E + e] = wide_lds[w * wide_stride];
@@ -324,7 +344,9 @@ struct Lane {
         }
         if (!imaging) return C.full_availability;
         double s;
-        if (C.avail_any_order) {          // exact in any order: subtract the terms of the nodes being re-imaged
+        if (C.avail_uniform) {            // every node has the same term and sums are exact in any order (all reference samples: 1.0): no table read
+            s = C.full_sum - (double)imaging * C.avail_term0;
+        } else if (C.avail_any_order) {   // exact in any order: subtract the terms of the nodes being re-imaged
             s = C.full_sum;
 #pragma unroll
             for (int w = 0; w < WT; ++w) {
@@ -343,13 +365,16 @@ struct Lane {
     __device__ __forceinline__ void defender_scan(uint32_t step, uint32_t episode, const StepIO& io, uint64_t (&fresh)[WT]) {
         if (step % C.scan_frequency) return;
         uint32_t det = 0;
+        uint64_t reim[WT];                // re-imagable nodes as set words from the config (scalar loads), not a table read behind the step's stores
+#pragma unroll
+        for (int w = 0; w < WT; ++w) reim[w] = C.reimagable[w];
         for (uint32_t i = 0; i < C.scan_capacity; ++i) {
             int n = (int)floor(draw(i, step, episode, io) * (double)S.N);
             if (n >= (int)S.N) n = (int)S.N - 1;
             if (!rget<WT>(m[M_RUN], (uint32_t)n) || !rget<WT>(m[M_INST], (uint32_t)n)) continue;
             const double d = draw(C.scan_capacity + det, step, episode, io);
             det += 1;
-            if (!(d <= C.scan_probability) || !(NS((uint32_t)n)->flags & MCBS_NODE_REIMAGABLE)) continue;
+            if (!(d <= C.scan_probability) || !rget<WT>(reim, (uint32_t)n)) continue;
             reimage((uint32_t)n, fresh);
         }
     }
@@ -551,7 +576,7 @@ __device__ __forceinline__ void step_body(const DevState& S, const Topo& T, cons
         ln.props = pt & ROW_PROPS_MASK; ln.tags = (uint32_t)(pt >> 60);
         ln.ever = r0.z; ln.since = r0.w;
         STAMP(3);  // row landed
-        ln.template act<!PK, DEFK>(X, skip ? -1.0 : 0.0, kind, src, tgt, X ? (k0 ? a2 : (k1 ? cL + a3 : 0u)) : 0u, (X & k2) ? a3 : 0u, triple);
+        ln.template act<!PK, DEFK, !TOPO_LDS>(X, skip ? -1.0 : 0.0, kind, src, tgt, X ? (k0 ? a2 : (k1 ? cL + a3 : 0u)) : 0u, (X & k2) ? a3 : 0u, triple);
         // unchanged rows are written back as they were
         if (PK) reinterpret_cast<uint32_t*>(body + S.off_rows)[tgt] = S.tiny_pack(ln.props, ln.tags, ln.ever, ln.since);
         else {

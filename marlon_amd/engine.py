@@ -23,7 +23,7 @@ EXPORTS = [
     "mcbs_last_error", "mcbs_abi_version", "mcbs_topology_create", "mcbs_topology_destroy", "mcbs_batch_create",
     "mcbs_batch_destroy", "mcbs_reset", "mcbs_step", "mcbs_step_observe", "mcbs_observe", "mcbs_observe_masked", "mcbs_action_mask", "mcbs_step_info",
     "mcbs_step_many", "mcbs_rollout_random", "mcbs_attacker_wrapper_post", "mcbs_attacker_wrapper_clear", "mcbs_defender_wrapper_post", "mcbs_sample_actions", "mcbs_decode_attacker_actions", "mcbs_defender_step", "mcbs_defender_observe", "mcbs_set_draw_tape", "mcbs_state_record_bytes", "mcbs_get_state", "mcbs_set_state",
-    "mcbs_timing_enable", "mcbs_timing_read",
+    "mcbs_timing_enable", "mcbs_timing_read", "mcbs_mask_logits", "mcbs_discrete_action_count",
 ]
 
 _lib = None
@@ -76,6 +76,9 @@ def load_library(path: Optional[str] = None):
     lib.mcbs_state_record_bytes.argtypes = [C.c_void_p]
     lib.mcbs_get_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     lib.mcbs_set_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.mcbs_discrete_action_count.restype = C.c_uint64
+    lib.mcbs_discrete_action_count.argtypes = [C.c_void_p]
+    lib.mcbs_mask_logits.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_size_t, C.c_float, C.c_void_p]
     lib.mcbs_timing_enable.argtypes = [C.c_void_p, C.c_int32]
     lib.mcbs_timing_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     for name in EXPORTS:
@@ -297,6 +300,23 @@ class BatchEngine:
             self._h, src.data_ptr() if multidiscrete is not None else None, src.data_ptr() if discrete is not None else None,
             actions_out.data_ptr(), invalid_out.data_ptr(), self._stream()), "mcbs_decode_attacker_actions")
         return actions_out, invalid_out
+
+    def discrete_action_count(self) -> int:
+        """Size of MaskedDiscreteAttackerWrapper's Discrete space: N*N*P*C + N*L + N*N*R (action_masking.py:74-80)."""
+        return int(self.lib.mcbs_discrete_action_count(self._h))
+
+    def mask_logits(self, logits, fill: float = -1e8):
+        """In place: logits[e, a] = mask(e, a) ? logits[e, a] : fill for the Discrete action mask of the LAST observation call
+        (step_observe / observe / action_mask), rebuilt on the device from that call's per-env digest — the mask itself is never
+        written.  logits: device float32 or bfloat16 [E, >= discrete_action_count()], rows contiguous."""
+        t = self.torch
+        if logits.dtype not in (t.float32, t.bfloat16):
+            raise ValueError("logits must be float32 or bfloat16")
+        if logits.dim() != 2 or logits.shape[0] != self.E or logits.stride(1) != 1 or logits.device != self.device:
+            raise ValueError(f"logits must be a device tensor [{self.E}, A] with contiguous rows")
+        _check(self.lib, self.lib.mcbs_mask_logits(self._h, logits.data_ptr(), 0 if logits.dtype == t.float32 else 1, logits.stride(0),
+                                                   float(fill), self._stream()), "mcbs_mask_logits")
+        return logits
 
     # -- learned defender (batches created with defender=("external",)) --
     def alloc_defender_obs(self) -> dict:

@@ -41,7 +41,7 @@ class AttackerVecEnv:
                  defender_goal=DefenderGoal(eviction=True), defender_constraint=DefenderConstraint(maintain_sla=0.0),
                  winning_reward=5000.0, losing_reward=0.0, max_timesteps: int = 2000, invalid_action_reward_modifier=-1,
                  discrete: bool = False, auto_reset: bool = True, device: Optional[str] = None, seed: int = 0,
-                 env_id_base: int = 0, rng_kind: int = 0, learned_defender: bool = False):
+                 env_id_base: int = 0, rng_kind: int = 0, learned_defender: bool = False, materialize_masks: bool = True):
         from .engine import BatchEngine
         self.topo: FlatTopology = initial_environment if isinstance(initial_environment, FlatTopology) else flatten(initial_environment)
         # the wrapper owns truncation and resets (its clock counts invalid actions too), so the engine's own are off
@@ -65,7 +65,11 @@ class AttackerVecEnv:
         self.nvec = np.array([3, N, L, N, N, R, N, N, P, Cm], dtype=np.int64)                      # attack_wrapper.py:206-227
         self.discrete_n = N * N * P * Cm + N * L + N * N * R                                         # action_masking.py:74-80
         dev = self.engine.device
-        self._obs = self.engine.alloc_obs(FLAT_FIELDS)
+        # materialize_masks=False: the three action masks (94 % of the observation's bytes) are not written at all; a policy applies them
+        # to its logits with mask_logits() (mcbs_mask_logits: rebuilt on the device from the observation's digest).  The observation
+        # dict then has no local_vulnerability / remote_vulnerability / connect entries and action_masks() raises.
+        self.materialize_masks = bool(materialize_masks)
+        self._obs = self.engine.alloc_obs(FLAT_FIELDS if self.materialize_masks else FLAT_FIELDS[:-1])
         self._terminal = {k: t.zeros_like(v) for k, v in self._obs.items()}
         self._mask_split = (N * N * P * Cm, N * L, (N, N, P, Cm), (N, L), (N, N, R))
         self._rows = t.zeros((n_envs, 5), dtype=t.int32, device=dev)
@@ -89,13 +93,16 @@ class AttackerVecEnv:
     # -- observation plumbing --
     def _public(self, obs: Dict[str, object]) -> Dict[str, object]:
         M, ML, s_connect, s_local, s_remote = self._mask_split
-        flat = obs["mask_discrete"]
-        out = {"local_vulnerability": flat[:, M:M + ML].unflatten(1, s_local), "remote_vulnerability": flat[:, M + ML:].unflatten(1, s_remote),
-               "connect": flat[:, :M].unflatten(1, s_connect),
+        out = {}
+        if "mask_discrete" in obs:
+            flat = obs["mask_discrete"]
+            out = {"local_vulnerability": flat[:, M:M + ML].unflatten(1, s_local), "remote_vulnerability": flat[:, M + ML:].unflatten(1, s_remote),
+                   "connect": flat[:, :M].unflatten(1, s_connect)}
+        out.update({
                "leaked_credentials": obs["leaked_credentials"].reshape(self.num_envs, -1),
                "credential_cache_matrix": obs["credential_cache_matrix"].reshape(self.num_envs, -1),
                "discovered_nodes_properties": obs["discovered_nodes_properties"].reshape(self.num_envs, -1),
-               "nodes_privilegelevel": obs["nodes_privilegelevel"]}
+               "nodes_privilegelevel": obs["nodes_privilegelevel"]})
         for i, k in enumerate(SCALAR_KEYS):
             out[k] = obs["scalars"][:, i]
         return out
@@ -110,7 +117,14 @@ class AttackerVecEnv:
 
     def action_masks(self):
         """[n_envs, N*N*P*C + N*L + N*N*R] bool, MaskedDiscreteAttackerWrapper order (connect, local, remote)."""
+        if not self.materialize_masks:
+            raise RuntimeError("this AttackerVecEnv was created with materialize_masks=False: apply the mask with mask_logits(logits)")
         return self._obs["mask_discrete"].view(self.torch.bool)      # the int8 mask holds 0 / 1 only: a bool view, no second gigabyte
+
+    def mask_logits(self, logits, fill: float = -1e8):
+        """`where(action_masks(), logits, fill)` in place on the device, without the mask: what MaskablePPO's MaskableCategorical does
+        with action_masks() (train_marl_multi.py:259-293), straight from the digest of the observation this env last returned."""
+        return self.engine.mask_logits(logits, fill)
 
     # -- VecEnv surface --
     def reset(self):
