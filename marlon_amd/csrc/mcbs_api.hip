@@ -69,7 +69,7 @@ struct mcbs_batch {
     StepCfg* C_dev = nullptr;       // device copy read by the step kernel through the scalar cache
     uint32_t* ere_lists_dev = nullptr;
     // developer switches, read ONCE at batch creation (getenv on every launch costs more than the launch itself)
-    bool no_lds_topo = false, no_fused_masks = false, slow_masks = false, no_row_masks = false;
+    bool lds_topo = false, no_fused_masks = false, slow_masks = false, no_row_masks = false;
     uint32_t step_block_override = 0;
     uint8_t* arena = nullptr;       // every per-env column + bodies + init body, one allocation
     size_t arena_bytes = 0;
@@ -203,8 +203,10 @@ extern "C" int mcbs_topology_create(const void* blob, size_t nbytes, int32_t dev
         L.payload = take(sizeof(mcbs_payload) * (h->n_payload + 1));
         // authorisation table replacing the service / allowed-credential lists (actions.py:608-621): per (node, port) the set
         // of credential strings that some RUNNING service on that port accepts (service state never changes, mcbs_defend.hip)
+        // ... indexed by the TRIPLE id of the cached credential the action names (bit t: the credential string of triple t is accepted),
+        // so that the look-up does not wait for the triple -> credential-string load
         const uint32_t P1 = h->n_ports ? h->n_ports : 1u;
-        L.auth_words = (h->n_cred_strings + 63u) / 64u ? (h->n_cred_strings + 63u) / 64u : 1u;
+        L.auth_words = (h->n_triples + 63u) / 64u ? (h->n_triples + 63u) / 64u : 1u;
         L.auth = take(sizeof(uint64_t) * (size_t)N * P1 * L.auth_words);
         L.triple = take(sizeof(mcbs_triple) * (h->n_triples + 1));
         L.avail = take(sizeof(double) * N);
@@ -227,6 +229,7 @@ extern "C" int mcbs_topology_create(const void* blob, size_t nbytes, int32_t dev
                     const mcbs_vuln_slot& v = sl[(size_t)n * h->max_slots + s];
                     d.cost = v.cost; d.probe_mask = v.probe_mask; d.payload_off = v.payload_off; d.payload_cnt = v.payload_cnt;
                     d.precond_tt = v.precond_tt; d.kind = v.kind; d.level = v.level; d.slot = s;
+                    for (uint32_t i = 0; i < 4u && i < v.payload_cnt; ++i) d.inline_payload[i] = pl[v.payload_off + i];
                 }
                 memcpy(hb + L.desc + sizeof(HotDesc) * ((size_t)n * W + c), &d, sizeof(d));
             }
@@ -239,7 +242,8 @@ extern "C" int mcbs_topology_create(const void* blob, size_t nbytes, int32_t dev
                 if (!sv[i].running) continue;
                 for (uint32_t k = 0; k < sv[i].allowed_cnt; ++k) {
                     const uint32_t c = allowed[sv[i].allowed_off + k];
-                    if (c < h->n_cred_strings) auth[((size_t)n * P1 + sv[i].port) * L.auth_words + (c >> 6)] |= 1ull << (c & 63u);
+                    for (uint32_t t3 = 0; t3 < h->n_triples; ++t3)         // every cached credential that carries this string
+                        if (tr[t3].cred == c) auth[((size_t)n * P1 + sv[i].port) * L.auth_words + (t3 >> 6)] |= 1ull << (t3 & 63u);
                 }
             }
         memcpy(hb + L.triple, tr, sizeof(mcbs_triple) * h->n_triples);
@@ -302,7 +306,7 @@ extern "C" int mcbs_batch_create(const mcbs_topology* topo, const mcbs_batch_cfg
     if (!b) return fail(MCBS_ENOMEM, "out of memory");
     b->topo = topo;
     b->cfg = *cfg;
-    b->no_lds_topo = getenv("MCBS_NO_LDS_TOPO") != nullptr; b->no_fused_masks = getenv("MCBS_NO_FUSED_MASKS") != nullptr;
+    b->lds_topo = getenv("MCBS_LDS_TOPO") != nullptr; b->no_fused_masks = getenv("MCBS_NO_FUSED_MASKS") != nullptr;
     b->slow_masks = getenv("MCBS_SLOW_MASKS") != nullptr; b->no_row_masks = getenv("MCBS_NO_ROW_MASKS") != nullptr;
     if (const char* ov = getenv("MCBS_STEP_BLOCK")) b->step_block_override = (uint32_t)atoi(ov);   // experiments only (64, 128 or 256)
     const uint32_t E = cfg->n_envs, N = h->n_nodes;
@@ -532,10 +536,16 @@ static int timing_end(mcbs_batch* b, hipStream_t st, size_t slot) {
 template <int PHASE, int WT, int DEF, bool MANY = false>
 static void launch_step_v(mcbs_batch* b, const StepIO& io, hipStream_t st, const RollArgs& roll = RollArgs{}) {
     const uint32_t E = b->S.E, lds = b->C.hot_bytes;
-    if (lds <= 60000u && !b->no_lds_topo) {
+    // Where the step kernel reads the topology's hot image from.  Measured on MI355X (profiles/round2_notes.md, tools/sweep_shapes.sh):
+    // through L1 / L2 with 64-thread workgroups beats a per-workgroup LDS copy at every BASELINE shape — 5.4 vs 5.6 us at 65 536 Chain-10
+    // envs, 5.5 vs 7.4 us for the Chain-100 shard (45 KB image, 128 wavefronts), 7.8 vs 8.5 us for Random-256 — once no table read is left
+    // behind a store (leak payload prefetched, defender look-ups from scalars).  One-wavefront workgroups spread over all CUs; a copy per
+    // workgroup only pays when many wavefronts share it, and then the image is L1-resident anyway.  MCBS_LDS_TOPO=1 selects the staged
+    // variant (images up to 60 KB) for experiments.
+    if (b->lds_topo && lds <= 60000u) {
         // workgroup size: as large as still leaves one workgroup per CU (256) — every workgroup stages its own copy of the hot
-        // image, so at 65 536 envs 64-thread workgroups re-read it 4x as often as 256-thread ones (5.79 vs 5.48 us/step), while
-        // 512 threads would leave half of the CUs idle (6.29 us)
+        // image, so at 65 536 envs 64-thread workgroups re-read it 4x as often as 256-thread ones, while 512 threads would leave half
+        // of the CUs idle
         uint32_t block = lds <= 8192u ? 64u : 256u;
         while (block < 256u && E / (block * 2u) >= 256u) block *= 2u;
         if (b->step_block_override) block = b->step_block_override;
@@ -543,7 +553,7 @@ static void launch_step_v(mcbs_batch* b, const StepIO& io, hipStream_t st, const
         if constexpr (MANY) hipLaunchKernelGGL((step_many_kernel<WT, true, DEF>), dim3((E + block - 1) / block), dim3(block), shm, st, b->S, b->T, b->C_dev, io, roll);
         else hipLaunchKernelGGL((step_kernel<PHASE, WT, true, DEF>), dim3((E + block - 1) / block), dim3(block), shm, st, b->S, b->T, b->C_dev, io);
     } else {
-        uint32_t block = 128u;
+        uint32_t block = E <= 65536u ? 64u : 256u;       // (beyond one wavefront per SIMD the shape no longer matters: 22.7 vs 22.2 us at 131 072 Random-256 envs)
         if (b->step_block_override) block = b->step_block_override;
         const uint32_t shm = b->S.wide ? block * b->S.TW * 8u : 0u;
         if constexpr (MANY) hipLaunchKernelGGL((step_many_kernel<WT, false, DEF>), dim3((E + block - 1) / block), dim3(block), shm, st, b->S, b->T, b->C_dev, io, roll);

@@ -41,7 +41,12 @@ __global__ __launch_bounds__(128) void defender_kernel(DevState S, Topo T, const
     for (int w = 0; w < WT; ++w) { back[w] = S.ring[((ln.dclk & 15u) * WT + (uint32_t)w) * S.E + e]; fresh[w] = 0ull; }
 
     // ---- is_defender_action_valid, on the state BEFORE this turn's tick ----
-    const int64_t* a = actions + (size_t)e * 12;
+    // all twelve components are loaded, then picked with selects: a divergent branch on the loaded kind whose arms load different
+    // components into the same variables is what ROCm 7.2's compiler mis-structurised in decode_kernel (tools/decode_repro/README.md)
+    const int64_t* ap = actions + (size_t)e * 12;
+    int64_t a[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) a[i] = ap[i];
     const int kind = (int)a[0];
     if (kind <= -2) {                                                // env not taking part in this turn (e.g. its episode just ended)
         if (valid_out) valid_out[e] = 0;

@@ -36,9 +36,11 @@ struct Row {            // 16 bytes
 static_assert(sizeof(Row) == 16, "row");
 constexpr uint64_t ROW_PROPS_MASK = (1ull << 60) - 1ull;
 
-// "Hot image": the part of the topology the step kernel reads, re-packed for it on the host at batch creation and
-// staged in LDS by every workgroup.  One 32-byte record per node and one 32-byte descriptor per (node, vulnerability
-// column): the slot_of -> slot indirection of the interchange blob is flattened away.
+// "Hot image": the part of the topology the step kernel reads, re-packed for it on the host at topology creation (read through
+// L1 / L2; optionally staged in LDS by every workgroup).  One 32-byte record per node and one 64-byte descriptor per (node,
+// vulnerability column): the slot_of -> slot indirection of the interchange blob is flattened away, the head of the leak payload
+// is inline, and the authorisation table is indexed by the cached credential's TRIPLE id, so that every table address depends on
+// the decoded action only (one level of loads).
 struct HotNode {        // 32 bytes
     uint64_t props;     // static properties that become known when the node is owned
     int32_t  value;
@@ -46,15 +48,17 @@ struct HotNode {        // 32 bytes
     uint16_t svc_off, svc_cnt;
     uint8_t  flags, pad[3];
 };
-struct HotDesc {        // 32 bytes; kind == 0xFF: the node does not have this vulnerability
+struct HotDesc {        // 64 bytes; kind == 0xFF: the node does not have this vulnerability
     double   cost;
     uint64_t probe_mask;
     uint32_t payload_off;
     uint16_t payload_cnt, precond_tt;
     uint8_t  kind, level, slot, pad;
     uint32_t pad2;
+    mcbs_payload inline_payload[4];   // the first four LeakedCredentials / LeakedNodesId entries, so that a leak needs no load that
+                                      // depends on the descriptor (longer lists continue in the payload section)
 };
-static_assert(sizeof(HotNode) == 32 && sizeof(HotDesc) == 32, "hot records");
+static_assert(sizeof(HotNode) == 32 && sizeof(HotDesc) == 64 && sizeof(mcbs_payload) == 8, "hot records");
 
 // node-set and credential-set columns, [word][env] u64 each
 enum { M_DISC = 0, M_INST, M_EVER, M_RUN, M_PLO, M_PHI, M_GATH, M_CACH, M_COUNT };

@@ -163,9 +163,7 @@ struct Lane {
     //            `port` / `triple` = connect arguments (0 for exploits).  Every index is valid for every lane.
     // WIDE_OK = false: the batch cannot have a wide cached-triple set (packed layout); compiles its handling out.
     // DK: the batch's defender kind; MCBS_DEFENDER_RANDOM_EVENTS consults the env's own vulnerability / service / firewall state
-    // GLOBAL_TB: the hot image is read from global memory (not staged in LDS): every table read must then be ISSUED before the step's
-    // first store — a load behind a store waits for the store's write acknowledgement — so the leak payload is fetched up front
-    template <bool WIDE_OK, int DK, bool GLOBAL_TB>
+    template <bool WIDE_OK, int DK>
     __device__ __forceinline__ void act(bool X, double raw_nx, int kind, uint32_t src, uint32_t tgt, uint32_t col, uint32_t port, uint32_t triple) {
         const bool k2 = kind == 2;
         // ---- look-ups of both flavours (LDS) ----
@@ -174,10 +172,10 @@ struct Lane {
         const uint64_t t_props = (uint64_t)t0.x | ((uint64_t)t0.y << 32);
         const int t_value = (int)t0.z;
         const uint32_t src_fw_out = NS(src)->fw_out_allow;
-        const uint32_t cred = (reinterpret_cast<const mcbs_triple*>(tb + C.hot_triple) + triple)->cred;
-        const uint64_t auth = reinterpret_cast<const uint64_t*>(tb + C.hot_auth)[(tgt * C.P + port) * C.auth_words + (cred >> 6)];
+        const uint64_t auth = reinterpret_cast<const uint64_t*>(tb + C.hot_auth)[(tgt * C.P + port) * C.auth_words + (triple >> 6)];
         const uint4* dp = reinterpret_cast<const uint4*>(tb + C.hot_desc + (tgt * (C.L + C.R) + col) * (uint32_t)sizeof(HotDesc));
         const uint4 d0 = dp[0], d1 = dp[1];   // {cost lo,hi, probe lo,hi} {payload_off, cnt | tt << 16, kind | level << 8 | slot << 16, -}
+        const uint4 d2 = dp[2], d3 = dp[3];   // the first four payload entries {node | cred << 16, triple | port << 16} x 2, x 2
 
         const bool src_owned = rget<WT>(m[M_INST], src);
         const bool running = rget<WT>(m[M_RUN], tgt);
@@ -194,7 +192,7 @@ struct Lane {
                 in_ok = mine ? (((fw_tgt >> r) & (fw_tgt >> (6u + r)) & 1u) != 0) : in_ok;     // fw_tgt: the target's INCOMING list
             }
         }
-        bool authorized = (auth >> (cred & 63u)) & 1ull;                                        // actions.py:608-621, precomputed per (node, port)
+        bool authorized = (auth >> (triple & 63u)) & 1ull;                                      // actions.py:608-621, precomputed per (node, port, cached credential)
         uint64_t own_present = ~0ull;
         if (DK == MCBS_DEFENDER_RANDOM_EVENTS) {               // (slow path by design: loops over the env's own tables in memory)
             const EreView V{body, C, ere_blob, S.N};
@@ -203,7 +201,7 @@ struct Lane {
                 const uint32_t* lists = reinterpret_cast<const uint32_t*>(tb + C.hot_fwlist);
                 out_ok = V.passes(lists[src] >> 16, port);
                 in_ok = V.passes(lists[tgt] & 0xFFFFu, port);
-                authorized = V.authorized(tgt, port, cred);
+                authorized = V.authorized(tgt, port, (reinterpret_cast<const mcbs_triple*>(tb + C.hot_triple) + triple)->cred);
             }
         }
         const bool reach = out_ok & in_ok & (bool)((t1.y >> port) & 1u);                        // not BLOCKED_BY_*_FIREWALL, not SCANNING_UNOPEN_PORT
@@ -264,15 +262,14 @@ struct Lane {
         const bool stage = wide && cnt != 0u && creds;
         if (stage)
             for (uint32_t w = 0; w < S.TW; ++w) wide_lds[w * wide_stride] = S.cach[(size_t)w * S.E + e];
-        constexpr uint32_t PF = 8;                       // payload entries fetched before the first store (longer lists: the tail loop loads)
-        uint2 pre[PF];
-        if (GLOBAL_TB) {
+        // The first four entries came with the descriptor; entries 4..7 are fetched now, before the first store (a load behind a store
+        // waits for the store's write acknowledgement), wave-uniformly skipped when no lane has that many; longer lists: the tail loop.
+        constexpr uint32_t PF = 8;
+        uint2 pre[PF] = {make_uint2(d2.x, d2.y), make_uint2(d2.z, d2.w), make_uint2(d3.x, d3.y), make_uint2(d3.z, d3.w),
+                         make_uint2(0u, 0u), make_uint2(0u, 0u), make_uint2(0u, 0u), make_uint2(0u, 0u)};
 #pragma unroll
-            for (uint32_t i = 0; i < PF; ++i) {
-                pre[i] = make_uint2(0u, 0u);
-                if (__ballot(i < cnt)) pre[i] = pl[i < cnt ? i : 0u];     // wave-uniform skip; the loads of one wave go out back to back
-            }
-        }
+        for (uint32_t i = 4; i < PF; ++i)
+            if (__ballot(i < cnt)) pre[i] = pl[i < cnt ? i : 0u];
         auto leak = [&](const uint2 p) {                 // one LeakedCredentials / LeakedNodesId entry {node | cred << 16, triple | port << 16}
             const uint32_t pn = p.x & 0xFFFFu, pc = p.x >> 16, pt = p.y & 0xFFFFu;
             // appends go to the slot past the list's end whether or not the element is new (the lists have one slack slot):
@@ -294,16 +291,12 @@ struct Lane {
             for (int w = 0; w < WT; ++w) { m[M_DISC][w] |= b0[w]; m[M_GATH][w] |= b1[w]; m[M_CACH][w] |= b2[w]; }
             n_disc += new_n; nn += new_n; nc += new_g; n_creds += new_c; ncache += new_c;
         };
-        if (GLOBAL_TB) {
 #pragma unroll
-            for (uint32_t i = 0; i < PF; ++i) {
-                if (!__ballot(i < cnt)) break;
-                if (i < cnt) leak(pre[i]);
-            }
-            for (uint32_t i = PF; i < cnt; ++i) leak(pl[i]);
-        } else {
-            for (uint32_t i = 0; i < cnt; ++i) leak(pl[i]);
+        for (uint32_t i = 0; i < PF; ++i) {
+            if (!__ballot(i < cnt)) break;
+            if (i < cnt) leak(pre[i]);
         }
+        for (uint32_t i = PF; i < cnt; ++i) leak(pl[i]);
         if (stage)
             for (uint32_t w = 0; w < S.TW; ++w) S.cach[(size_t)w * S.E + e] = wide_lds[w * wide_stride];
         rx += 5 * (int)nn + 3 * (int)nc;
@@ -576,7 +569,7 @@ __device__ __forceinline__ void step_body(const DevState& S, const Topo& T, cons
         ln.props = pt & ROW_PROPS_MASK; ln.tags = (uint32_t)(pt >> 60);
         ln.ever = r0.z; ln.since = r0.w;
         STAMP(3);  // row landed
-        ln.template act<!PK, DEFK, !TOPO_LDS>(X, skip ? -1.0 : 0.0, kind, src, tgt, X ? (k0 ? a2 : (k1 ? cL + a3 : 0u)) : 0u, (X & k2) ? a3 : 0u, triple);
+        ln.template act<!PK, DEFK>(X, skip ? -1.0 : 0.0, kind, src, tgt, X ? (k0 ? a2 : (k1 ? cL + a3 : 0u)) : 0u, (X & k2) ? a3 : 0u, triple);
         // unchanged rows are written back as they were
         if (PK) reinterpret_cast<uint32_t*>(body + S.off_rows)[tgt] = S.tiny_pack(ln.props, ln.tags, ln.ever, ln.since);
         else {

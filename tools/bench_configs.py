@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Step-only timing of BASELINE.json's configurations (per-GPU shard for the 8-GPU ones): hipGraph replay of recorded valid-action
 batches on a fresh engine, HIP events on the launch stream (tools/workloads.py — the same code path bench.py's `configs` leg uses).
-    python tools/bench_configs.py [K] [workload ...]        one JSON line per workload; developer switches (MCBS_NO_LDS_TOPO,
+    python tools/bench_configs.py [K] [workload ...]        one JSON line per workload; developer switches (MCBS_LDS_TOPO,
     MCBS_STEP_BLOCK, MCBS_NO_PACKED_SETS ...) are read by the library at batch creation and echoed in the line."""
 import json
 import os
