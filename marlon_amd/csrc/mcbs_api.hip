@@ -832,20 +832,26 @@ extern "C" int mcbs_mask_logits(mcbs_batch* b, void* logits, int32_t dtype, size
     G.M = G.N * G.N * G.RL; G.ML = G.N * G.L; G.A = (uint32_t)A64;
     G.dRL = fast_div_host(G.RL); G.dC = fast_div_host(G.C); G.dN = fast_div_host(G.N); G.dL = fast_div_host(G.L); G.dR = fast_div_host(G.R);
     constexpr int U = 4;
-    const dim3 grid((G.A + 256u * 4u * U - 1u) / (256u * 4u * U), b->S.E), block(256);
     hipStream_t st = (hipStream_t)stream;
-    const size_t esz = dtype == MCBS_LOGITS_F32 ? 4 : 2;
-    const bool vec = row_stride % 4 == 0 && reinterpret_cast<uintptr_t>(logits) % (4 * esz) == 0;
+    const uintptr_t p0 = reinterpret_cast<uintptr_t>(logits);
+    auto grid_for = [&](uint32_t gw) { return dim3((G.A + 256u * gw * U - 1u) / (256u * gw * U), b->S.E); };
+    const dim3 block(256);
+#define MCBS_LOGITS_LAUNCH(LT_, GW_, VEC_, PTR_, FILL_) \
+    hipLaunchKernelGGL((mask_logits_kernel<LT_, GW_, U, VEC_>), grid_for(GW_), block, 0, st, b->S, b->T, b->C_dev, b->digest, PTR_, row_stride, FILL_, G)
     if (dtype == MCBS_LOGITS_F32) {
-        if (vec) hipLaunchKernelGGL((mask_logits_kernel<float, U, true>), grid, block, 0, st, b->S, b->T, b->C_dev, b->digest, static_cast<float*>(logits), row_stride, fill, G);
-        else hipLaunchKernelGGL((mask_logits_kernel<float, U, false>), grid, block, 0, st, b->S, b->T, b->C_dev, b->digest, static_cast<float*>(logits), row_stride, fill, G);
+        float* lp = static_cast<float*>(logits);
+        if ((row_stride * 4) % 16 == 0 && p0 % 16 == 0) MCBS_LOGITS_LAUNCH(float, 4u, true, lp, fill);
+        else MCBS_LOGITS_LAUNCH(float, 4u, false, lp, fill);
     } else {
         uint32_t bits;                                   // float -> bfloat16, round to nearest even
         memcpy(&bits, &fill, 4);
         const uint16_t f16 = (bits & 0x7FFFFFFFu) > 0x7F800000u ? (uint16_t)((bits >> 16) | 0x40u) : (uint16_t)((bits + 0x7FFFu + ((bits >> 16) & 1u)) >> 16);
-        if (vec) hipLaunchKernelGGL((mask_logits_kernel<uint16_t, U, true>), grid, block, 0, st, b->S, b->T, b->C_dev, b->digest, static_cast<uint16_t*>(logits), row_stride, f16, G);
-        else hipLaunchKernelGGL((mask_logits_kernel<uint16_t, U, false>), grid, block, 0, st, b->S, b->T, b->C_dev, b->digest, static_cast<uint16_t*>(logits), row_stride, f16, G);
+        uint16_t* lp = static_cast<uint16_t*>(logits);
+        if ((row_stride * 2) % 16 == 0 && p0 % 16 == 0) MCBS_LOGITS_LAUNCH(uint16_t, 8u, true, lp, f16);
+        else if ((row_stride * 2) % 8 == 0 && p0 % 8 == 0) MCBS_LOGITS_LAUNCH(uint16_t, 4u, true, lp, f16);     // rows only 8-byte aligned (Chain-10: 14 172 actions)
+        else MCBS_LOGITS_LAUNCH(uint16_t, 4u, false, lp, f16);
     }
+#undef MCBS_LOGITS_LAUNCH
     return launch_ok("mask logits");
 }
 

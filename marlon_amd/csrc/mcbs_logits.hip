@@ -8,8 +8,9 @@
 // per-env digest the last observation left (owned-source bits by external index, discovered-node and cached-credential
 // counts, blank flag: exactly what the mask bytes of THAT observation were computed from), so the mask never exists in memory:
 //     logits[e, a] = mask(e, a) ? logits[e, a] : fill
-// One workgroup per (env, slice of 256 * 4 * UNROLL actions); a thread owns UNROLL groups of 4 consecutive actions (16 bytes of
-// fp32 / 8 bytes of bf16 logits): all its loads are issued before its first store.  Bound: HBM read + write of the logits.
+// One workgroup per (env, slice of 256 * UNROLL groups); a thread owns UNROLL groups of 16 bytes of logits (4 fp32 / 8 bf16 actions):
+// all its loads are issued before its first store, and the mask bits of a group come from ONE division chain (the connect block is
+// periodic).  Bound: HBM read + write of the logits.
 #pragma once
 #include "mcbs_device.h"
 #include "mcbs_obs.hip"
@@ -21,14 +22,13 @@ struct LogitsGeom {        // Discrete layout of the batch, set up on the host
     FastDiv dRL, dC, dN, dL, dR;
 };
 
-template <typename T> struct Vec4;
-template <> struct Vec4<float> { using type = float4; };
-template <> struct Vec4<uint16_t> { using type = ushort4; };     // bf16 / fp16 logits: 16-bit patterns, only moved or replaced
-
-template <typename LT, int UNROLL, bool VEC>
+// LT: float, or uint16_t for 16-bit logits (bf16 patterns are only moved or replaced).  GW: actions per group = per vector access
+// (16 bytes: 4 fp32 / 8 bf16; 8-byte groups of 4 bf16 when the rows are only 8-byte aligned, e.g. Chain-10's 14 172 actions).
+template <typename LT, uint32_t GW, int UNROLL, bool VEC>
 __global__ __launch_bounds__(256) void mask_logits_kernel(DevState S, Topo T, const StepCfg* __restrict__ Cp, const ObsDigest* __restrict__ digest,
                                                           LT* __restrict__ logits, size_t row_stride, LT fill, LogitsGeom G) {
-    using V = typename Vec4<LT>::type;
+    constexpr uint32_t NWORD = GW * (uint32_t)sizeof(LT) / 4u;      // dwords per group: 4 or 2
+    static_assert(NWORD == 4u || NWORD == 2u, "group = 16 or 8 bytes");
     const uint32_t e = blockIdx.y;
     const ObsDigest d = digest[e];                       // uniform per workgroup: scalar loads
     const uint32_t n_disc = d.blank ? 0u : d.n_disc, n_creds = d.n_creds;
@@ -38,46 +38,74 @@ __global__ __launch_bounds__(256) void mask_logits_kernel(DevState S, Topo T, co
         const uint32_t s = fdiv(q, G.dN), t = q - s * G.N;
         return own(s) && t < n_disc;
     };
-    const uint32_t base = (blockIdx.x * 256u * UNROLL + threadIdx.x) * 4u;
-    V v[UNROLL];
+    auto mask_at = [&](uint32_t a) -> bool {             // one action, any region
+        if (a < G.M) {                                   // connect[s][t][p][c] = on(s, t) && c < n_creds      (env.py:664-677)
+            const uint32_t q = fdiv(a, G.dRL), r = a - q * G.RL, c = r - fdiv(r, G.dC) * G.C;
+            return c < n_creds && pair_on(q);
+        }
+        if (a < G.M + G.ML) {                            // local[i][l] = owned(i) && vulnerability l applies to node i   (env.py:653-663)
+            const uint32_t b = a - G.M, i = fdiv(b, G.dL), l = b - i * G.L;
+            if (!(own(i) && i < n_disc)) return false;
+            const uint8_t* body = S.body + (size_t)e * S.body_stride;
+            const mcbs_node_static* NS = reinterpret_cast<const mcbs_node_static*>(T.base + Cp->off_node);
+            return (NS[body[S.off_disc + i]].local_mask >> l) & 1u;
+        }
+        return a < G.A && pair_on(fdiv(a - G.M - G.ML, G.dR));   // remote[s][t][r] = on(s, t)
+    };
+    const uint32_t base = (blockIdx.x * 256u * UNROLL + threadIdx.x) * GW;
+    uint32_t v[UNROLL][4];
     bool have[UNROLL];
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {                   // all loads first
-        const uint32_t a0 = base + (uint32_t)u * 1024u;
-        have[u] = VEC && a0 + 4u <= G.A;                 // VEC: rows start 16-byte (8-byte for 16-bit logits) aligned
-        if (have[u]) v[u] = *reinterpret_cast<const V*>(row + a0);
+        const uint32_t a0 = base + (uint32_t)u * 256u * GW;
+        have[u] = VEC && a0 + GW <= G.A;                 // VEC: rows start aligned to the group size
+        v[u][0] = v[u][1] = v[u][2] = v[u][3] = 0u;
+        if (have[u]) {
+            if constexpr (NWORD == 4u) { const uint4 t4 = *reinterpret_cast<const uint4*>(row + a0); v[u][0] = t4.x; v[u][1] = t4.y; v[u][2] = t4.z; v[u][3] = t4.w; }
+            else { const uint2 t2 = *reinterpret_cast<const uint2*>(row + a0); v[u][0] = t2.x; v[u][1] = t2.y; }
+        }
     }
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
-        const uint32_t a0 = base + (uint32_t)u * 1024u;
+        const uint32_t a0 = base + (uint32_t)u * 256u * GW;
         if (a0 >= G.A) continue;
-        bool m[4];
+        uint32_t m = 0;                                  // bit j: action a0 + j is allowed
+        if (a0 + GW <= G.M && G.C >= 4u && G.RL >= GW) {
+            // the whole group lies in the connect block (all but the last ~2 % of a row): one division chain per GROUP — the group
+            // touches at most two (source, target) rows, and the credential index just counts on modulo C (RL is a multiple of C)
+            const uint32_t q0 = fdiv(a0, G.dRL), r0 = a0 - q0 * G.RL, c0 = r0 - fdiv(r0, G.dC) * G.C;
+            const bool on0 = pair_on(q0), on1 = pair_on(q0 + 1u);
 #pragma unroll
-        for (uint32_t j = 0; j < 4u; ++j) {
-            const uint32_t a = a0 + j;
-            bool on = false;
-            if (a < G.M) {                               // connect[s][t][p][c] = on(s, t) && c < n_creds      (env.py:664-677)
-                const uint32_t q = fdiv(a, G.dRL), r = a - q * G.RL, c = r - fdiv(r, G.dC) * G.C;
-                on = c < n_creds && pair_on(q);
-            } else if (a < G.M + G.ML) {                 // local[i][l] = owned(i) && vulnerability l applies to node i   (env.py:653-663)
-                const uint32_t b = a - G.M, i = fdiv(b, G.dL), l = b - i * G.L;
-                if (own(i) && i < n_disc) {
-                    const uint8_t* body = S.body + (size_t)e * S.body_stride;
-                    const mcbs_node_static* NS = reinterpret_cast<const mcbs_node_static*>(T.base + Cp->off_node);
-                    on = (NS[body[S.off_disc + i]].local_mask >> l) & 1u;
-                }
-            } else if (a < G.A) {                        // remote[s][t][r] = on(s, t)
-                on = pair_on(fdiv(a - G.M - G.ML, G.dR));
+            for (uint32_t j = 0; j < GW; ++j) {
+                uint32_t c = c0 + j;
+                c -= c >= G.C ? G.C : 0u;
+                c -= c >= G.C ? G.C : 0u;
+                const bool on = (r0 + j >= G.RL) ? on1 : on0;
+                m |= (uint32_t)(on && c < n_creds) << j;
             }
-            m[j] = on;
+        } else {
+#pragma unroll
+            for (uint32_t j = 0; j < GW; ++j) m |= (uint32_t)mask_at(a0 + j) << j;
         }
         if (have[u]) {
-            V o = v[u];
-            o.x = m[0] ? o.x : fill; o.y = m[1] ? o.y : fill; o.z = m[2] ? o.z : fill; o.w = m[3] ? o.w : fill;
-            *reinterpret_cast<V*>(row + a0) = o;
+            uint32_t o[4] = {v[u][0], v[u][1], v[u][2], v[u][3]};
+            if constexpr (sizeof(LT) == 4) {
+                const uint32_t f = __float_as_uint(fill);
+#pragma unroll
+                for (uint32_t w = 0; w < NWORD; ++w) o[w] = ((m >> w) & 1u) ? o[w] : f;
+            } else {
+                const uint32_t f = (uint32_t)fill, ff = f | (f << 16);
+#pragma unroll
+                for (uint32_t w = 0; w < NWORD; ++w) {    // two 16-bit patterns per dword
+                    const uint32_t b2 = m >> (2u * w), keep = ((b2 & 1u) ? 0x0000FFFFu : 0u) | ((b2 & 2u) ? 0xFFFF0000u : 0u);
+                    o[w] = (o[w] & keep) | (ff & ~keep);
+                }
+            }
+            if constexpr (NWORD == 4u) *reinterpret_cast<uint4*>(row + a0) = make_uint4(o[0], o[1], o[2], o[3]);
+            else *reinterpret_cast<uint2*>(row + a0) = make_uint2(o[0], o[1]);
         } else {                                         // unaligned rows, and the last (partial) group of a row
-            for (uint32_t j = 0; j < 4u && a0 + j < G.A; ++j)
-                if (!m[j]) row[a0 + j] = fill;
+            for (uint32_t j = 0; j < GW && a0 + j < G.A; ++j)
+                if (!((m >> j) & 1u)) row[a0 + j] = fill;
         }
     }
 }
