@@ -555,10 +555,7 @@ static void launch_step_v(mcbs_batch* b, const StepIO& io, hipStream_t st, const
     } else {
         uint32_t block = E <= 65536u ? 64u : 256u;       // (beyond one wavefront per SIMD the shape no longer matters: 22.7 vs 22.2 us at 131 072 Random-256 envs)
         if (b->step_block_override) block = b->step_block_override;
-        // WT >= 2: the env's sets live in LDS (mcbs_step.hip Lane<WT, LS>): (8 sets + 1 scratch) x WT words x 8 bytes per lane
-        const uint32_t per_wave = WT >= 2 ? (uint32_t)(M_COUNT + 1) * (uint32_t)WT * 64u * 8u : 0u;
-        while (per_wave && block > 64u && (block / 64u) * per_wave + (b->S.wide ? block * b->S.TW * 8u : 0u) > 64u * 1024u) block /= 2u;
-        const uint32_t shm = (block / 64u) * per_wave + (b->S.wide ? block * b->S.TW * 8u : 0u);
+        const uint32_t shm = b->S.wide ? block * b->S.TW * 8u : 0u;
         if constexpr (MANY) hipLaunchKernelGGL((step_many_kernel<WT, false, DEF>), dim3((E + block - 1) / block), dim3(block), shm, st, b->S, b->T, b->C_dev, io, roll);
         else hipLaunchKernelGGL((step_kernel<PHASE, WT, false, DEF>), dim3((E + block - 1) / block), dim3(block), shm, st, b->S, b->T, b->C_dev, io);
     }

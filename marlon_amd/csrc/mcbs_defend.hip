@@ -25,7 +25,7 @@ __global__ __launch_bounds__(128) void defender_kernel(DevState S, Topo T, const
     const uint4 h0 = S.h0[e];
     double2 h1 = S.h1[e];
     uint8_t* body = S.body + (size_t)e * S.body_stride;
-    Lane<WT, false> ln{S, C, T.hot, e, body, h0.z & 0xFFFFu, h0.z >> 16, h0.w & 0xFFFFu, h0.w >> 16, {}, 0u, 0ull, 0u, 0u, 0u, false, true, 0u, 0u,
+    Lane<WT> ln{S, C, T.hot, e, body, h0.z & 0xFFFFu, h0.z >> 16, h0.w & 0xFFFFu, h0.w >> 16, {}, 0u, 0ull, 0u, 0u, 0u, false, true, 0u, 0u,
                 0.0, MCBS_OUT_NONE, 0, 0, 0};
     uint64_t m0[M_COUNT][WT];
 #pragma unroll
@@ -36,9 +36,9 @@ __global__ __launch_bounds__(128) void defender_kernel(DevState S, Topo T, const
             m0[k][w] = wanted ? S.get(k, (uint32_t)w, e) : 0ull;
             ln.m[k][w] = m0[k][w];
         }
-    uint64_t back[WT];
+    uint64_t back[WT], fresh[WT];
 #pragma unroll
-    for (int w = 0; w < WT; ++w) back[w] = S.ring[((ln.dclk & 15u) * WT + (uint32_t)w) * S.E + e];
+    for (int w = 0; w < WT; ++w) { back[w] = S.ring[((ln.dclk & 15u) * WT + (uint32_t)w) * S.E + e]; fresh[w] = 0ull; }
 
     // ---- is_defender_action_valid, on the state BEFORE this turn's tick ----
     // all twelve components are loaded, then picked with selects: a divergent branch on the loaded kind whose arms load different
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(128) void defender_kernel(DevState S, Topo T, const
     }
     // ---- executeAction: the tick first, always ----
     h1.y = ln.defender_tick(back);
-    if (ok && kind == 0) ln.reimage((uint32_t)node);
+    if (ok && kind == 0) ln.reimage((uint32_t)node, fresh);
     else if (ok && kind == 1) fwp[l_examined] = (uint16_t)(fw & ~((1u | (1u << 6)) << rule));            // every rule with that name is removed
     else if (ok && kind == 2 && rule >= 0 && rule < 6 && !((fw >> rule) & 1u)) {
         // the examined list has no such rule: an ALLOW rule is appended to the node's INCOMING list; it becomes that list's
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(128) void defender_kernel(DevState S, Topo T, const
     // stop_service / start_service: valid, and without effect in the reference (defender.py:45-48 vs actions.py:782-794)
 #pragma unroll
     for (int w = 0; w < WT; ++w)
-        if (ln.fresh[w] != back[w]) S.ring[((ln.dclk & 15u) * WT + (uint32_t)w) * S.E + e] = ln.fresh[w];
+        if (fresh[w] != back[w]) S.ring[((ln.dclk & 15u) * WT + (uint32_t)w) * S.E + e] = fresh[w];
     ln.dclk = (ln.dclk + 1u) & 0xFFFFu;
     S.h0[e] = make_uint4(h0.x, h0.y, h0.z, ln.owned | (ln.dclk << 16));
     S.h1[e] = h1;

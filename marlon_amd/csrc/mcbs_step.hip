@@ -115,12 +115,7 @@ __device__ __forceinline__ uint32_t dword_of(const uint4& r0, const uint4& r1, c
 }
 
 // ------------------------------ per-lane working set ------------------------------
-// LS: the env's sets live in LDS instead of registers (general layout with WT >= 2: Chain-100, Random-256).  A set access then is one
-// ds_read / ds_write of the word the node index selects; with the words in registers that selection is mask arithmetic over all WT
-// words of the set (a select chain is turned into a scratch array by the compiler), and at WT = 4 those ~30 instructions per access
-// were most of the step's ALU time (profiles/round2_notes.md).  Layout: word w of set k of lane l at ls[(k * WT + w) * 64], ls already
-// offset by the lane: conflict-free across the lanes of a wavefront whatever words they pick.  Set M_COUNT is the scratch set `fresh`.
-template <int WT, bool LS = false>
+template <int WT>
 struct Lane {
     const DevState& S;
     const StepCfg& C;
@@ -128,7 +123,7 @@ struct Lane {
     uint32_t e;
     uint8_t* body;
     uint32_t n_disc, n_creds, owned, dclk;
-    uint64_t m[M_COUNT][LS ? 1 : WT];   // (register mode)
+    uint64_t m[M_COUNT][WT];
     uint32_t dirty;      // defender paths: bit k = set k changed and must be written back
     // the target node's row, in registers
     uint64_t props;      // discovered properties (60 bits)
@@ -144,29 +139,6 @@ struct Lane {
     uint64_t* wide_lds = nullptr;
     uint32_t wide_stride = 0;
     const uint8_t* ere_blob = nullptr;   // the topology blob (ExternalRandomEvents reads its cold tables)
-    uint64_t* ls = nullptr;              // LS: this lane's column of the wavefront's set area in LDS
-    uint64_t fresh[LS ? 1 : WT] = {};    // nodes re-imaged at this defender tick (register mode; LS: set M_COUNT)
-
-    // ---- set access, whichever home the sets have ----
-    __device__ __forceinline__ uint64_t& lw(int k, uint32_t w) const { return ls[((uint32_t)k * WT + w) * 64u]; }
-    __device__ __forceinline__ bool sget(int k, uint32_t n) const {
-        if constexpr (LS) return (lw(k, n >> 6) >> (n & 63u)) & 1ull; else return rget<WT>(m[k], n);
-    }
-    __device__ __forceinline__ void sor(int k, uint32_t n, bool on) {         // bit n of set k |= on
-        if constexpr (LS) lw(k, n >> 6) |= on ? (1ull << (n & 63u)) : 0ull;
-        else {
-            uint64_t b[WT];
-            rbit<WT>(b, n, on);
-#pragma unroll
-            for (int w = 0; w < WT; ++w) m[k][w] |= b[w];
-        }
-    }
-    __device__ __forceinline__ void sclr(int k, uint32_t n) {
-        if constexpr (LS) lw(k, n >> 6) &= ~(1ull << (n & 63u)); else rclear<WT>(m[k], n);
-    }
-    __device__ __forceinline__ uint64_t sword(int k, int w) const { if constexpr (LS) return lw(k, (uint32_t)w); else return m[k][w]; }
-    __device__ __forceinline__ void sword_put(int k, int w, uint64_t v) { if constexpr (LS) lw(k, (uint32_t)w) = v; else m[k][w] = v; }
-    __device__ __forceinline__ uint64_t fresh_word(int w) const { if constexpr (LS) return lw(M_COUNT, (uint32_t)w); else return fresh[w]; }
 
     __device__ __forceinline__ const HotNode* NS(uint32_t n) const { return reinterpret_cast<const HotNode*>(tb + C.hot_node) + n; }
     __device__ __forceinline__ Row* row(uint32_t n) const { return reinterpret_cast<Row*>(body + S.off_rows) + n; }
@@ -174,19 +146,11 @@ struct Lane {
     __device__ __forceinline__ uint16_t* cred_list() const { return reinterpret_cast<uint16_t*>(body + S.off_cred); }
 
     __device__ __forceinline__ uint32_t privilege(uint32_t n) const {
-        return (uint32_t)sget(M_PLO, n) | ((uint32_t)sget(M_PHI, n) << 1);
+        return (uint32_t)rget<WT>(m[M_PLO], n) | ((uint32_t)rget<WT>(m[M_PHI], n) << 1);
     }
     __device__ __forceinline__ void set_privilege(uint32_t n, uint32_t p) {
-        if constexpr (LS) {
-            const uint64_t bit = 1ull << (n & 63u);
-            uint64_t& lo = lw(M_PLO, n >> 6);
-            uint64_t& hi = lw(M_PHI, n >> 6);
-            lo = (lo & ~bit) | ((p & 1u) ? bit : 0ull);
-            hi = (hi & ~bit) | ((p & 2u) ? bit : 0ull);
-        } else {
-            if (p & 1u) rset<WT>(m[M_PLO], n); else rclear<WT>(m[M_PLO], n);
-            if (p & 2u) rset<WT>(m[M_PHI], n); else rclear<WT>(m[M_PHI], n);
-        }
+        if (p & 1u) rset<WT>(m[M_PLO], n); else rclear<WT>(m[M_PLO], n);
+        if (p & 2u) rset<WT>(m[M_PHI], n); else rclear<WT>(m[M_PHI], n);
         dirty |= (1u << M_PLO) | (1u << M_PHI);
     }
 
@@ -213,9 +177,9 @@ struct Lane {
         const uint4 d0 = dp[0], d1 = dp[1];   // {cost lo,hi, probe lo,hi} {payload_off, cnt | tt << 16, kind | level << 8 | slot << 16, -}
         const uint4 d2 = dp[2], d3 = dp[3];   // the first four payload entries {node | cred << 16, triple | port << 16} x 2, x 2
 
-        const bool src_owned = sget(M_INST, src);
-        const bool running = sget(M_RUN, tgt);
-        const bool already = sget(M_INST, tgt);
+        const bool src_owned = rget<WT>(m[M_INST], src);
+        const bool running = rget<WT>(m[M_RUN], tgt);
+        const bool already = rget<WT>(m[M_INST], tgt);
 
         // ---- connect_to_remote_machine checks, in the reference's order: firewalls (-10), listening (-10), running (0),
         // credentials (-10: WRONG_PASSWORD); target discovered / credential gathered hold by construction (own lists) ----
@@ -264,28 +228,19 @@ struct Lane {
         // ---- __mark_node_as_owned (actions.py:251-275): `already` = currently owned (agent installed); a node that is
         // owned now was owned before, so only a change of ownership consults / sets the ever-owned bit ----
         const bool newly = go & !already & (k2 | esc | (vk == MCBS_OUT_LATERAL_MOVE));
-        const bool first_time = newly & !sget(M_EVER, tgt);
+        const bool first_time = newly & !rget<WT>(m[M_EVER], tgt);
         const uint32_t priv = privilege(tgt);
         const uint32_t np = priv > own_level ? priv : own_level;   // model.escalate
         const bool chg = newly & (np != priv);
-        if constexpr (LS) {                                     // one word per set: the one holding the target's bit
-            const uint32_t wi = tgt >> 6;
-            const uint64_t bit = 1ull << (tgt & 63u), bnw = newly ? bit : 0ull, bcw = chg ? bit : 0ull;
-            lw(M_EVER, wi) |= bnw;
-            lw(M_INST, wi) |= bnw;
-            lw(M_PLO, wi) = (lw(M_PLO, wi) & ~bcw) | ((np & 1u) ? bcw : 0ull);
-            lw(M_PHI, wi) = (lw(M_PHI, wi) & ~bcw) | ((np & 2u) ? bcw : 0ull);
-        } else {
-            uint64_t bn[WT], bc[WT];
-            rbit<WT>(bn, tgt, newly);
-            rbit<WT>(bc, tgt, chg);
+        uint64_t bn[WT], bc[WT];
+        rbit<WT>(bn, tgt, newly);
+        rbit<WT>(bc, tgt, chg);
 #pragma unroll
-            for (int w = 0; w < WT; ++w) {
-                m[M_EVER][w] |= bn[w];
-                m[M_INST][w] |= bn[w];
-                m[M_PLO][w] = (m[M_PLO][w] & ~bc[w]) | ((np & 1u) ? bc[w] : 0ull);
-                m[M_PHI][w] = (m[M_PHI][w] & ~bc[w]) | ((np & 2u) ? bc[w] : 0ull);
-            }
+        for (int w = 0; w < WT; ++w) {
+            m[M_EVER][w] |= bn[w];
+            m[M_INST][w] |= bn[w];
+            m[M_PLO][w] = (m[M_PLO][w] & ~bc[w]) | ((np & 1u) ? bc[w] : 0ull);
+            m[M_PHI][w] = (m[M_PHI][w] & ~bc[w]) | ((np & 2u) ? bc[w] : 0ull);
         }
         owned += (chg & (priv == 0u)) ? 1u : 0u;
         props |= newly ? t_props : 0ull;                        // all (non-tag) properties become known
@@ -319,18 +274,21 @@ struct Lane {
             const uint32_t pn = p.x & 0xFFFFu, pc = p.x >> 16, pt = p.y & 0xFFFFu;
             // appends go to the slot past the list's end whether or not the element is new (the lists have one slack slot):
             // the count only advances for a new element, so a stale write is overwritten or never read
-            const bool new_n = !sget(M_DISC, pn);
-            const bool new_g = creds & !sget(M_GATH, pc);
+            const bool new_n = !rget<WT>(m[M_DISC], pn);
+            const bool new_g = creds & !rget<WT>(m[M_GATH], pc);
             bool new_c;
             if (wide) {
                 uint64_t* w = wide_lds + (pt >> 6) * wide_stride;
                 const uint64_t old = stage ? *w : 0ull, bit = 1ull << (pt & 63u);
                 new_c = creds & !(old & bit);
                 if (stage) *w = old | bit;
-            } else new_c = creds & !sget(M_CACH, pt & (WT * 64u - 1u));
+            } else new_c = creds & !rget<WT>(m[M_CACH], pt);
             disc_list()[n_disc] = (uint8_t)pn;
             cred_list()[n_creds] = (uint16_t)pt;
-            sor(M_DISC, pn, new_n); sor(M_GATH, pc & (WT * 64u - 1u), new_g); sor(M_CACH, pt & (WT * 64u - 1u), new_c && !wide);
+            uint64_t b0[WT], b1[WT], b2[WT];
+            rbit<WT>(b0, pn, new_n); rbit<WT>(b1, pc, new_g); rbit<WT>(b2, pt & (WT * 64u - 1u), new_c && !wide);
+#pragma unroll
+            for (int w = 0; w < WT; ++w) { m[M_DISC][w] |= b0[w]; m[M_GATH][w] |= b1[w]; m[M_CACH][w] |= b2[w]; }
             n_disc += new_n; nn += new_n; nc += new_g; n_creds += new_c; ncache += new_c;
         };
 #pragma unroll
@@ -353,18 +311,12 @@ struct Lane {
     }
 
     // ---- defender ----
-    // One Philox4x32-10 block yields the two doubles 2b and 2b+1 of a step; the block last computed is kept, so consecutive draws
-    // (scan draws 0..k-1, then the detection draws) cost one block per PAIR — the ten rounds of 32x32->64 multiplies are what a scanning
-    // step of the defender spends most of its time in (profiles/round2_notes.md)
-    uint32_t rng_block = 0xFFFFFFFFu, rng_w[4] = {0u, 0u, 0u, 0u};
-    __device__ __forceinline__ double draw(uint32_t i, uint32_t step, uint32_t episode, const StepIO& io) {
+    __device__ __forceinline__ double draw(uint32_t i, uint32_t step, uint32_t episode, const StepIO& io) const {
         if (C.rng_kind == MCBS_RNG_TAPE) return (io.tape && i < io.tape_dps) ? io.tape[(size_t)e * io.tape_dps + i] : 0.0;
-        if ((i >> 1) != rng_block) {
-            const uint64_t gid = C.env_id_base + e;
-            philox4x32_10((uint32_t)gid, episode, step, i >> 1, (uint32_t)C.seed, (uint32_t)(C.seed >> 32) ^ (uint32_t)(gid >> 32), rng_w);
-            rng_block = i >> 1;
-        }
-        return (i & 1u) ? to_double53(rng_w[2], rng_w[3]) : to_double53(rng_w[0], rng_w[1]);
+        const uint64_t gid = C.env_id_base + e;
+        uint32_t r[4];
+        philox4x32_10((uint32_t)gid, episode, step, i >> 1, (uint32_t)C.seed, (uint32_t)(C.seed >> 32) ^ (uint32_t)(gid >> 32), r);
+        return (i & 1u) ? to_double53(r[2], r[3]) : to_double53(r[0], r[1]);
     }
 
     __device__ __forceinline__ uint64_t valid_bits(uint32_t w) const {
@@ -380,9 +332,8 @@ struct Lane {
         uint32_t imaging = 0;
 #pragma unroll
         for (int w = 0; w < WT; ++w) {
-            const uint64_t r = sword(M_RUN, w) | back[w];
-            if (back[w]) { sword_put(M_RUN, w, r); dirty |= 1u << M_RUN; }
-            imaging += __popcll(~r & valid_bits(w));
+            if (back[w]) { m[M_RUN][w] |= back[w]; dirty |= 1u << M_RUN; }
+            imaging += __popcll(~m[M_RUN][w] & valid_bits(w));
         }
         if (!imaging) return C.full_availability;
         double s;
@@ -392,19 +343,19 @@ struct Lane {
             s = C.full_sum;
 #pragma unroll
             for (int w = 0; w < WT; ++w) {
-                uint64_t im = ~sword(M_RUN, w) & valid_bits(w);
+                uint64_t im = ~m[M_RUN][w] & valid_bits(w);
                 while (im) { const uint32_t b = (uint32_t)__builtin_ctzll(im); im &= im - 1; s -= avail_term(w * 64u + b); }
             }
         } else {                          // the reference's node-order sum
             s = 0.0;
-            for (uint32_t n = 0; n < S.N; ++n) if (sget(M_RUN, n)) s += avail_term(n);
+            for (uint32_t n = 0; n < S.N; ++n) if (rget<WT>(m[M_RUN], n)) s += avail_term(n);
         }
         return s / C.total_sla_weight;
     }
 
     // ScanAndReimageCompromisedMachines.step (defender.py:42-55) + reimage_node (actions.py:700-712).
     // Nodes re-imaged now are collected in `fresh`: they come back 16 ticks from now (same ring slot).
-    __device__ __forceinline__ void defender_scan(uint32_t step, uint32_t episode, const StepIO& io) {
+    __device__ __forceinline__ void defender_scan(uint32_t step, uint32_t episode, const StepIO& io, uint64_t (&fresh)[WT]) {
         if (step % C.scan_frequency) return;
         uint32_t det = 0;
         uint64_t reim[WT];                // re-imagable nodes as set words from the config (scalar loads), not a table read behind the step's stores
@@ -413,23 +364,23 @@ struct Lane {
         for (uint32_t i = 0; i < C.scan_capacity; ++i) {
             int n = (int)floor(draw(i, step, episode, io) * (double)S.N);
             if (n >= (int)S.N) n = (int)S.N - 1;
-            if (!sget(M_RUN, (uint32_t)n) || !sget(M_INST, (uint32_t)n)) continue;
+            if (!rget<WT>(m[M_RUN], (uint32_t)n) || !rget<WT>(m[M_INST], (uint32_t)n)) continue;
             const double d = draw(C.scan_capacity + det, step, episode, io);
             det += 1;
             if (!(d <= C.scan_probability) || !rget<WT>(reim, (uint32_t)n)) continue;
-            reimage((uint32_t)n);
+            reimage((uint32_t)n, fresh);
         }
     }
 
     // reimage_node (actions.py:700-712): agent removed, privilege NoAccess, Imaging for REIMAGING_DURATION ticks; tags,
     // discovered properties and credentials stay (quirk Q6)
-    __device__ __forceinline__ void reimage(uint32_t n) {
+    __device__ __forceinline__ void reimage(uint32_t n, uint64_t (&fresh)[WT]) {
         if (S.packed) reinterpret_cast<uint32_t*>(body + S.off_rows)[n] &= (1u << (S.tiny_p + 4u + S.tiny_v)) - 1u;
         else row(n)->since = 0;                               // every earlier attack now predates last_reimaging
-        sclr(M_INST, n);
+        rclear<WT>(m[M_INST], n);
         if (privilege(n)) { set_privilege(n, 0u); owned -= 1; }
-        sclr(M_RUN, n);
-        if constexpr (LS) sor(M_COUNT, n, true); else rset<WT>(fresh, n);
+        rclear<WT>(m[M_RUN], n);
+        rset<WT>(fresh, n);
         dirty |= (1u << M_INST) | (1u << M_RUN);
     }
 };
@@ -444,7 +395,6 @@ template <int PHASE, int WTP, bool TOPO_LDS, int DEFK, bool MANY>
 __device__ __forceinline__ void step_body(const DevState& S, const Topo& T, const StepCfg* __restrict__ Cp, const StepIO& io, const RollArgs& roll) {
     constexpr bool PK = WTP == 0;           // packed batch: the eight sets are 16-bit fields of one uint4 per env
     constexpr int WT = PK ? 1 : WTP;
-    constexpr bool LS = !PK && WT >= 2 && !TOPO_LDS;   // the env's sets live in LDS (see Lane)
     const StepCfg& C = *Cp;   // in device memory: fields are fetched by scalar loads where they are used, not all up front
     extern __shared__ uint4 topo_lds[];
 #ifdef MCBS_DIAG
@@ -566,26 +516,15 @@ __device__ __forceinline__ void step_body(const DevState& S, const Topo& T, cons
     const bool skip_env = PHASE == 2 ? (old_flags & F_SKIP) != 0 : (int)a03.x == MCBS_ACTION_SKIP;
     const bool live = !ended & !skip_env;
 
-    Lane<WT, LS> ln{S, C, tb, ec, body, h0.z & 0xFFFFu, h0.z >> 16, h0.w & 0xFFFFu, h0.w >> 16, {}, 0u, 0ull, 0u, 0u, 0u, false, learned, 0u, 0u,
-                    0.0, MCBS_OUT_NONE, 0, 0, 0};
-    if constexpr (LS) {                                 // sets -> this wavefront's LDS area (each lane only ever touches its own column)
-        ln.ls = reinterpret_cast<uint64_t*>(topo_lds) + (threadIdx.x >> 6) * ((uint32_t)(M_COUNT + 1) * WT * 64u) + (threadIdx.x & 63u);
+    Lane<WT> ln{S, C, tb, ec, body, h0.z & 0xFFFFu, h0.z >> 16, h0.w & 0xFFFFu, h0.w >> 16, {}, 0u, 0ull, 0u, 0u, 0u, false, learned, 0u, 0u,
+                0.0, MCBS_OUT_NONE, 0, 0, 0};
 #pragma unroll
-        for (int k = 0; k < M_COUNT; ++k)
+    for (int k = 0; k < M_COUNT; ++k)
 #pragma unroll
-            for (int w = 0; w < WT; ++w) ln.lw(k, (uint32_t)w) = m0[k][w];
-#pragma unroll
-        for (int w = 0; w < WT; ++w) ln.lw(M_COUNT, (uint32_t)w) = 0ull;
-    } else {
-#pragma unroll
-        for (int k = 0; k < M_COUNT; ++k)
-#pragma unroll
-            for (int w = 0; w < WT; ++w) ln.m[k][w] = m0[k][w];
-    }
+        for (int w = 0; w < WT; ++w) ln.m[k][w] = m0[k][w];
     ln.ere_blob = T.base;
-    if (!PK && S.wide) {                                // this lane's LDS column for the wide cached-triple set, behind the hot image / the set area
-        const uint32_t skip16 = TOPO_LDS ? C.hot_bytes / 16u : (LS ? (blockDim.x >> 6) * ((uint32_t)(M_COUNT + 1) * WT * 64u) / 2u : 0u);
-        ln.wide_lds = reinterpret_cast<uint64_t*>(topo_lds + skip16) + threadIdx.x;
+    if (!PK && S.wide) {                                // this lane's LDS column for the wide cached-triple set, behind the hot image
+        ln.wide_lds = reinterpret_cast<uint64_t*>(topo_lds + (TOPO_LDS ? C.hot_bytes / 16u : 0u)) + threadIdx.x;
         ln.wide_stride = blockDim.x;
     }
     // level 2 (needs the header): this defender tick's ring slot
@@ -656,13 +595,14 @@ __device__ __forceinline__ void step_body(const DevState& S, const Topo& T, cons
         bool done = false;
         if (has_def) {
             if (live & !oob) {
-                h1.y = ln.defender_tick(back);
-                ln.defender_scan(step, episode, io);
+                uint64_t fresh[WT];
 #pragma unroll
-                for (int w = 0; w < WT; ++w) {     // the slot now holds the nodes re-imaged at this tick (released 16 ticks on)
-                    const uint64_t fw = ln.fresh_word(w);
-                    if (fw != back[w]) S.ring[((ln.dclk & 15u) * WT + (uint32_t)w) * S.E + e] = fw;
-                }
+                for (int w = 0; w < WT; ++w) fresh[w] = 0ull;
+                h1.y = ln.defender_tick(back);
+                ln.defender_scan(step, episode, io, fresh);
+#pragma unroll
+                for (int w = 0; w < WT; ++w)       // the slot now holds the nodes re-imaged at this tick (released 16 ticks on)
+                    if (fresh[w] != back[w]) S.ring[((ln.dclk & 15u) * WT + (uint32_t)w) * S.E + e] = fresh[w];
                 ln.dclk = (ln.dclk + 1u) & 0xFFFFu;
             }
         }
@@ -710,7 +650,7 @@ __device__ __forceinline__ void step_body(const DevState& S, const Topo& T, cons
             if (PHASE != 2 || has_def) {
                 uint32_t f[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) f[q] = (uint32_t)ln.sword(2 * q, 0) | ((uint32_t)ln.sword(2 * q + 1, 0) << 16);
+                for (int q = 0; q < 4; ++q) f[q] = (uint32_t)ln.m[2 * q][0] | ((uint32_t)ln.m[2 * q + 1][0] << 16);
                 reinterpret_cast<uint4*>(S.masks)[e] = make_uint4(f[0], f[1], f[2], f[3]);
             }
         } else {
@@ -720,10 +660,8 @@ __device__ __forceinline__ void step_body(const DevState& S, const Topo& T, cons
                 const bool defender_set = k == M_RUN || k == M_INST || k == M_PLO || k == M_PHI;
                 if (!((PHASE != 2 && attacker_set) || (PHASE != 1 && has_def && defender_set))) continue;
 #pragma unroll
-                for (int w = 0; w < WT; ++w) {
-                    const uint64_t v = ln.sword(k, w);
-                    if (WT == 1 || v != m0[k][w]) S.masks[((uint32_t)k * WT + (uint32_t)w) * S.E + e] = v;
-                }
+                for (int w = 0; w < WT; ++w)
+                    if (WT == 1 || ln.m[k][w] != m0[k][w]) S.masks[((uint32_t)k * WT + (uint32_t)w) * S.E + e] = ln.m[k][w];
             }
         }
     }

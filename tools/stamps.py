@@ -20,7 +20,7 @@ for wl in (sys.argv[1:] or ["headline"]):
     lib.mcbs_diag_set_stamps.argtypes = [C.c_void_p, C.c_void_p]
     waves = (eng.E + 63) // 64
     buf = torch.zeros((waves, 8), dtype=torch.int64, device=eng.device)
-    T = int(os.environ.get("STAMP_T", "120"))
+    T = 120
     for t in range(T):
         a = eng.sample_actions(True, seed=1, step=t)
         if t == T - 1:
