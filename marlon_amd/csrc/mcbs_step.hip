@@ -311,12 +311,17 @@ struct Lane {
     }
 
     // ---- defender ----
-    __device__ __forceinline__ double draw(uint32_t i, uint32_t step, uint32_t episode, const StepIO& io) const {
+    // One Philox4x32-10 block yields the two doubles 2b and 2b+1 of a step; the block last computed is kept, so consecutive draws
+    // (scan draws 0..k-1, then the detection draws) cost one block per PAIR
+    uint32_t rng_block = 0xFFFFFFFFu, rng_w[4] = {0u, 0u, 0u, 0u};
+    __device__ __forceinline__ double draw(uint32_t i, uint32_t step, uint32_t episode, const StepIO& io) {
         if (C.rng_kind == MCBS_RNG_TAPE) return (io.tape && i < io.tape_dps) ? io.tape[(size_t)e * io.tape_dps + i] : 0.0;
-        const uint64_t gid = C.env_id_base + e;
-        uint32_t r[4];
-        philox4x32_10((uint32_t)gid, episode, step, i >> 1, (uint32_t)C.seed, (uint32_t)(C.seed >> 32) ^ (uint32_t)(gid >> 32), r);
-        return (i & 1u) ? to_double53(r[2], r[3]) : to_double53(r[0], r[1]);
+        if ((i >> 1) != rng_block) {
+            const uint64_t gid = C.env_id_base + e;
+            philox4x32_10((uint32_t)gid, episode, step, i >> 1, (uint32_t)C.seed, (uint32_t)(C.seed >> 32) ^ (uint32_t)(gid >> 32), rng_w);
+            rng_block = i >> 1;
+        }
+        return (i & 1u) ? to_double53(rng_w[2], rng_w[3]) : to_double53(rng_w[0], rng_w[1]);
     }
 
     __device__ __forceinline__ uint64_t valid_bits(uint32_t w) const {
