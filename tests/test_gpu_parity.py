@@ -343,3 +343,44 @@ def test_set_state_round_trip_and_continuation():
     _compare_states(a.get_state(), b.get_state(), "continuation")
     a.close()
     b.close()
+
+
+def test_random_events_availability_bits_with_non_dyadic_weights():
+    """ExternalRandomEvents recomputes availability every step from the env's own service flags:
+    sum over nodes of sla_weight * (1 + running service weights) / (1 + all service weights), every product and sum rounded
+    separately like the reference's Python floats (actions.py:728-746).  Non-dyadic NODE and SERVICE weights and stopped services make
+    a fused multiply-add visible in the last bit; engine vs oracle as uint64 bit patterns, Philox draws, 1 024 envs."""
+    from marlon_amd import flatten as F, model
+    from marlon_amd._abi import RNG_PHILOX, EnvSpec
+    from marlon_amd.samples import kitchen_sink
+    from oracle.oracle import Oracle
+    env = kitchen_sink.build(model)
+    nw = [0.1, 0.3, 0.7, 1.9, 2.3, 0.6, 1.1, 3.3]
+    sw = [0.3, 0.6, 1.7, 0.9, 0.1, 2.2]
+    k = 0
+    for i, (_, info) in enumerate(env.nodes()):
+        info.sla_weight = nw[i % len(nw)]
+        for s in info.services:
+            s.sla_weight = sw[k % len(sw)]
+            k += 1
+    assert k >= 4
+    topo = F.flatten(env)
+    assert int(topo.header()["avail_any_order"]) == 0
+    E = 1024
+    spec = EnvSpec(n_envs=E, maximum_node_count=topo.n_nodes, maximum_total_credentials=max(1, len(topo.triples)),
+                   maximum_discoverable_credentials_per_action=8, attacker_goal=dict(own_atleast_percent=1.0), maintain_sla=0.0,
+                   defender=("random_events",), auto_reset=True, max_episode_steps=120, rng_kind=RNG_PHILOX, seed=4242, env_id_base=9)
+    eng = _engine().BatchEngine(topo, spec)
+    orc = Oracle(topo, spec)
+    distinct = set()
+    for t in range(240):
+        a = eng.sample_actions(t % 3 != 2, seed=8, step=t)
+        r, d = eng.step(a)
+        o = orc.step(a.cpu().numpy())
+        av = eng.info["network_availability"].cpu().numpy()
+        np.testing.assert_array_equal(av.view(np.uint64), o["availability"].view(np.uint64), err_msg=f"step {t} availability bits")
+        np.testing.assert_array_equal(r.double().cpu().numpy(), o["reward"], err_msg=f"step {t} reward")
+        np.testing.assert_array_equal(d.cpu().numpy(), o["terminated"], err_msg=f"step {t} terminated")
+        distinct.update(np.unique(av).tolist())
+    assert len(distinct) > 20 and min(distinct) < 0.9          # services were stopped: many different non-trivial sums were compared
+    eng.close()

@@ -55,6 +55,24 @@ def test_topology_create_rejects_malformed_blobs_without_gpu():
     bad[int(hdr["off_slot_of"])] = 200                                                     # slot index out of range
     assert lib.mcbs_topology_create(bad.ctypes.data, bad.size, 0, C.byref(out)) == -1
     assert lib.mcbs_step(None, None, None, None, None, None) == -1                          # null arguments
+    # firewall rule sections (read on the host at batch creation and by the random-events kernels): truncated / inconsistent blobs
+    from marlon_amd.samples import toy_ctf
+    blob = np.frombuffer(flatten.flatten(toy_ctf.new_environment()).blob, np.uint8).copy()
+    hdr = blob[:192].view(flatten.HEADER_DT)[0]
+    assert hdr["n_fw_lists"] > 0 and hdr["n_fw_rules"] > 0
+    bad = blob.copy()
+    bad[:192].view(flatten.HEADER_DT)[0]["off_fw_range"] = (int(hdr["total_bytes"]) // 16) * 16          # section starts at the end of the blob
+    assert lib.mcbs_topology_create(bad.ctypes.data, bad.size, 0, C.byref(out)) == -1 and b"fw_range" in lib.mcbs_last_error()
+    bad = blob.copy()
+    bad[:192].view(flatten.HEADER_DT)[0]["n_fw_rules"] = 1 << 30                                           # rule array far beyond the blob
+    assert lib.mcbs_topology_create(bad.ctypes.data, bad.size, 0, C.byref(out)) == -1 and b"fw_rule" in lib.mcbs_last_error()
+    bad = blob.copy()
+    fr = bad[int(hdr["off_fw_range"]):int(hdr["off_fw_range"]) + 4].view("<u2")
+    fr[1] = 60000                                                                                          # list 0 claims 60 000 rules
+    assert lib.mcbs_topology_create(bad.ctypes.data, bad.size, 0, C.byref(out)) == -1 and b"rule list" in lib.mcbs_last_error()
+    bad = blob.copy()
+    bad[int(hdr["off_fw_rule"])] = 250                                                                     # rule 0 names port 250 of n_names
+    assert lib.mcbs_topology_create(bad.ctypes.data, bad.size, 0, C.byref(out)) == -1 and b"port name" in lib.mcbs_last_error()
 
 
 def test_missing_library_fails_loudly(tmp_path):

@@ -93,6 +93,22 @@ def main():
             k = dict(kernel=name, calls=int(r[1]), avg_us=float(r[3]) / 1e3, min_us=float(r[5]) / 1e3, max_us=float(r[6]) / 1e3,
                      share_of_gpu_time_pct=float(r[4]), FETCH_SIZE_KiB_per_launch=f, WRITE_SIZE_KiB_per_launch=w,
                      pmc_dispatches=[nf, nw])
+            sq = {}
+            for sub, names in (("sqi", ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR")),
+                               ("sqc", ("SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"))):
+                for cn in names:
+                    val = counter_per_kernel(f"{d}/{sub}", cn).get(name)
+                    if val is not None:
+                        sq[cn] = val[0]
+            if sq.get("SQ_WAVES"):
+                wv = sq["SQ_WAVES"]
+                k["per_wave_instructions"] = {c[9:]: round(sq[c] / wv, 1) for c in sq if c.startswith("SQ_INSTS_")}
+                k["waves_per_launch"] = wv
+            if sq.get("SQ_WAVE_CYCLES"):
+                wc = sq["SQ_WAVE_CYCLES"]
+                k["wave_cycle_split"] = {"wave_cycles_per_launch": wc, "parked_at_waitcnt_or_barrier": round(sq.get("SQ_WAIT_ANY", 0) / wc, 3),
+                                         "issue_stalled": round(sq.get("SQ_WAIT_INST_ANY", 0) / wc, 3),
+                                         "issuing": round(sq.get("SQ_ACTIVE_INST_ANY", 0) / wc, 3)}
             if f is not None and w is not None:
                 k["hbm_bytes_per_launch"] = (2.0 * f + w) * 1024.0
                 if run.get("envs"):
@@ -110,7 +126,7 @@ def main():
             for r in rows[:10]:
                 r[0] = r[0][:140]
                 w.writerow(r)
-        for sub in ("stats", "fetch", "write"):
+        for sub in ("stats", "fetch", "write", "sqi", "sqc"):
             shutil.rmtree(f"{d}/{sub}", ignore_errors=True)
         for k in kernels[:4]:
             print(json.dumps({a: k.get(a) for a in ("kernel", "calls", "avg_us", "min_us", "hbm_bytes_per_env", "hbm_GBps_at_avg")}))

@@ -20,6 +20,10 @@ for w in "${wl[@]}"; do
     rocprofv3 --kernel-trace --stats --output-format csv -d "$d/stats" -o run -- python3 tools/profile_run.py "$w" $k > "$d/stats.log" 2>&1 || { echo "stats run failed for $w"; tail -5 "$d/stats.log"; exit 1; }
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$d/fetch" -o run -- python3 tools/profile_run.py "$w" $k > "$d/fetch.log" 2>&1 || { echo "fetch run failed for $w"; tail -5 "$d/fetch.log"; exit 1; }
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$d/write" -o run -- python3 tools/profile_run.py "$w" $k > "$d/write.log" 2>&1 || { echo "write run failed for $w"; tail -5 "$d/write.log"; exit 1; }
+    case "$w" in step:*)   # instruction mix and where the wavefronts' cycles go (SQ block: 8 counters per pass)
+        rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d "$d/sqi" -o run -- python3 tools/profile_run.py "$w" $k > "$d/sqi.log" 2>&1 || { echo "SQ instruction pass failed for $w"; tail -5 "$d/sqi.log"; }
+        rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d "$d/sqc" -o run -- python3 tools/profile_run.py "$w" $k > "$d/sqc.log" 2>&1 || { echo "SQ cycle pass failed for $w"; tail -5 "$d/sqc.log"; }
+        ;; esac
     # summarise on the spot and drop the bulky raw CSVs (gpurun_out is capped at 64 MiB)
     python3 tools/pmc_summary.py workload "$d" || exit 1
 done
