@@ -52,6 +52,11 @@ __global__ __launch_bounds__(256) void mask_logits_kernel(DevState S, Topo T, co
         }
         return a < G.A && pair_on(fdiv(a - G.M - G.ML, G.dR));   // remote[s][t][r] = on(s, t)
     };
+    uint64_t pp = 0;                                     // credential pattern of one period, repeated to at least C + GW bits (uniform per workgroup)
+    if (G.C + GW <= 64u) {
+        const uint64_t one = n_creds >= 64u ? ~0ull : ((1ull << n_creds) - 1ull);
+        for (uint32_t sh = 0; sh < 64u; sh += G.C) pp |= one << sh;
+    }
     const uint32_t base = (blockIdx.x * 256u * UNROLL + threadIdx.x) * GW;
     uint32_t v[UNROLL][4];
     bool have[UNROLL];
@@ -70,7 +75,16 @@ __global__ __launch_bounds__(256) void mask_logits_kernel(DevState S, Topo T, co
         const uint32_t a0 = base + (uint32_t)u * 256u * GW;
         if (a0 >= G.A) continue;
         uint32_t m = 0;                                  // bit j: action a0 + j is allowed
-        if (a0 + GW <= G.M && G.C >= 4u && G.RL >= GW) {
+        if (a0 + GW <= G.M && G.C + GW <= 64u && G.RL >= GW) {
+            // the whole group lies in the connect block and one credential period plus a group fits 64 bits (Chain-10: C = 12, ToyCtf: 10):
+            // `pp` = the periodic pattern "n_creds ones, C - n_creds zeros" as a bit string, so the group's credential bits are one shift;
+            // the group touches at most two (source, target) rows, each on or off as a whole
+            const uint32_t q0 = fdiv(a0, G.dRL), r0 = a0 - q0 * G.RL, c0 = r0 - fdiv(r0, G.dC) * G.C;
+            const uint32_t first = G.RL - r0 < GW ? G.RL - r0 : GW;                  // actions of the group that belong to row q0
+            const uint32_t lo = (1u << first) - 1u, all = (1u << GW) - 1u;
+            const uint32_t rows = (pair_on(q0) ? lo : 0u) | ((first < GW && pair_on(q0 + 1u)) ? (all & ~lo) : 0u);
+            m = (uint32_t)(pp >> c0) & rows;
+        } else if (a0 + GW <= G.M && G.C >= 4u && G.RL >= GW) {
             // the whole group lies in the connect block (all but the last ~2 % of a row): one division chain per GROUP — the group
             // touches at most two (source, target) rows, and the credential index just counts on modulo C (RL is a multiple of C)
             const uint32_t q0 = fdiv(a0, G.dRL), r0 = a0 - q0 * G.RL, c0 = r0 - fdiv(r0, G.dC) * G.C;
