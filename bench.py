@@ -48,7 +48,7 @@ ENVS_PER_GPU = 65536
 B_STEP = 348            # algorithmic bytes per env-step, SURVEY.md section 8(d) (attacker-only tier)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 METRIC = "env-steps/sec at 65536 envs, CyberBattleChain-10; bit-exact vs CPU ref"
-HEADLINE_KERNEL = "mcbs::step_kernel<0, 0, true, 0>"
+HEADLINE_KERNEL = "mcbs::step_kernel<0, 0, false, 0>"   # <PHASE whole step, packed sets, hot image through L1/L2, no defender>
 
 
 def parse_args(argv=None):
@@ -355,7 +355,7 @@ def main() -> int:
     if rank == 0:
         bytes_per_launch = float(B_STEP) * E
         achieved = bytes_per_launch / (kernel_us * 1e-6) / 1e9
-        traffic, tinfo = load_traffic("step_headline", "mcbs::step_kernel<0, 0, true, 0")
+        traffic, tinfo = load_traffic("step_headline", "mcbs::step_kernel<0, 0, false, 0")
         if traffic is not None and E != ENVS_PER_GPU:
             traffic, tinfo["status"] = None, "not applicable: counters were taken at 65 536 envs per launch"
         per_rank_value = [E * K / x for x in per_rank]

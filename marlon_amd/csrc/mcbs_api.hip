@@ -553,8 +553,8 @@ static void launch_step_v(mcbs_batch* b, const StepIO& io, hipStream_t st, const
         if constexpr (MANY) hipLaunchKernelGGL((step_many_kernel<WT, true, DEF>), dim3((E + block - 1) / block), dim3(block), shm, st, b->S, b->T, b->C_dev, io, roll);
         else hipLaunchKernelGGL((step_kernel<PHASE, WT, true, DEF>), dim3((E + block - 1) / block), dim3(block), shm, st, b->S, b->T, b->C_dev, io);
     } else {
-        uint32_t block = E <= 65536u ? 64u : 256u;       // (beyond one wavefront per SIMD the shape no longer matters: 22.7 vs 22.2 us at 131 072 Random-256 envs)
-        if (b->step_block_override) block = b->step_block_override;
+        const uint32_t block = 64u;                      // fixed (the kernel relies on it); beyond one wavefront per SIMD the shape no longer
+                                                         // matters: 22.7 (64) vs 22.2 us (256) at 131 072 Random-256 envs
         const uint32_t shm = b->S.wide ? block * b->S.TW * 8u : 0u;
         if constexpr (MANY) hipLaunchKernelGGL((step_many_kernel<WT, false, DEF>), dim3((E + block - 1) / block), dim3(block), shm, st, b->S, b->T, b->C_dev, io, roll);
         else hipLaunchKernelGGL((step_kernel<PHASE, WT, false, DEF>), dim3((E + block - 1) / block), dim3(block), shm, st, b->S, b->T, b->C_dev, io);

@@ -413,9 +413,11 @@ __device__ __forceinline__ void step_body(const DevState& S, const Topo& T, cons
     STAMP_NOWAIT(0);
     // action-space bounds as scalars, fetched now: left alone, the compiler turns `k1 ? C.R : C.P` into a per-lane VECTOR load
     // from the config (select of two loads -> load of the selected address), i.e. one more memory round trip after level 1
-    uint32_t cL = C.L, cR = C.R, cP = C.P;
-    asm volatile("" : "+s"(cL), "+s"(cR), "+s"(cP));
-    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    // (fetched and pinned AFTER the level-1 vector loads are issued, below: pinned here, the kernel waited for the kernel-argument
+    // load, then for this load through the config pointer, before its first vector load went out — a quarter of a wavefront's life)
+    // Workgroups of the L1 / L2 variant are always one wavefront (mcbs_api.hip): the env index needs no hidden-argument load
+    const uint32_t bdim = TOPO_LDS ? blockDim.x : 64u;
+    const uint32_t e = blockIdx.x * bdim + threadIdx.x;
     const bool active = e < S.E;
     const uint32_t ec = active ? e : 0u;                // clamp so inactive lanes read valid memory and take no branch
     constexpr bool has_def = DEFK == MCBS_DEFENDER_SCAN_AND_REIMAGE;   // in-env defender, resolved at launch
@@ -491,10 +493,12 @@ __device__ __forceinline__ void step_body(const DevState& S, const Topo& T, cons
     if (PHASE == 2) pending = S.pending[ec];
 
     STAMP_NOWAIT(1);   // level-1 loads issued
+    uint32_t cL = C.L, cR = C.R, cP = C.P;
+    asm volatile("" : "+s"(cL), "+s"(cR), "+s"(cP));
     if (!TOPO_LDS) tb = T.hot;
     if (TOPO_LDS && it == 0u) {                         // cooperative copy of the hot topology image, 16 bytes per lane
         const uint4* src = reinterpret_cast<const uint4*>(T.hot);
-        const uint32_t nvec = C.hot_bytes / 16u, bd = blockDim.x;
+        const uint32_t nvec = C.hot_bytes / 16u, bd = bdim;
         if (PK || nvec <= 2u * bd) {                    // small image (Chain-10: 1.1 passes): the plain loop is the fastest here; packed
                                                         // batches (<= 16 nodes) never have a large one, and their kernel keeps exactly this code
             for (uint32_t i = threadIdx.x; i < nvec; i += bd) topo_lds[i] = src[i];
@@ -530,7 +534,7 @@ __device__ __forceinline__ void step_body(const DevState& S, const Topo& T, cons
     ln.ere_blob = T.base;
     if (!PK && S.wide) {                                // this lane's LDS column for the wide cached-triple set, behind the hot image
         ln.wide_lds = reinterpret_cast<uint64_t*>(topo_lds + (TOPO_LDS ? C.hot_bytes / 16u : 0u)) + threadIdx.x;
-        ln.wide_stride = blockDim.x;
+        ln.wide_stride = bdim;
     }
     // level 2 (needs the header): this defender tick's ring slot
     uint64_t back[WT];
