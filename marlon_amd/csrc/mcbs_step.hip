@@ -176,6 +176,8 @@ struct Lane {
         const uint4* dp = reinterpret_cast<const uint4*>(tb + C.hot_desc + (tgt * (C.L + C.R) + col) * (uint32_t)sizeof(HotDesc));
         const uint4 d0 = dp[0], d1 = dp[1];   // {cost lo,hi, probe lo,hi} {payload_off, cnt | tt << 16, kind | level << 8 | slot << 16, -}
         const uint4 d2 = dp[2], d3 = dp[3];   // the first four payload entries {node | cred << 16, triple | port << 16} x 2, x 2
+        __builtin_amdgcn_sched_barrier(0);    // all eight table loads go out together: left alone, the scheduler sinks the descriptor's
+                                              // four below the first uses of the node record, i.e. behind a wait — one more round trip
 
         const bool src_owned = rget<WT>(m[M_INST], src);
         const bool running = rget<WT>(m[M_RUN], tgt);
@@ -270,6 +272,11 @@ struct Lane {
 #pragma unroll
         for (uint32_t i = 4; i < PF; ++i)
             if (__ballot(i < cnt)) pre[i] = pl[i < cnt ? i : 0u];
+        // Every load of the step has been issued by now and the stores start below.  Wait for ALL of them here, in straight-line code:
+        // the leak entries run under divergent control flow, and a wait the compiler has to place INSIDE it (it cannot prove that an
+        // entry's operands have landed) is `s_waitcnt vmcnt(0)` with the previous entry's stores in flight — a write-acknowledgement
+        // round trip per leaked entry (the vector memory counter retires loads and stores in order).
+        __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0), expcnt / lgkmcnt untouched
         auto leak = [&](const uint2 p) {                 // one LeakedCredentials / LeakedNodesId entry {node | cred << 16, triple | port << 16}
             const uint32_t pn = p.x & 0xFFFFu, pc = p.x >> 16, pt = p.y & 0xFFFFu;
             // appends go to the slot past the list's end whether or not the element is new (the lists have one slack slot):
