@@ -501,7 +501,16 @@ __device__ __forceinline__ void step_body(const DevState& S, const Topo& T, cons
 
     STAMP_NOWAIT(1);   // level-1 loads issued
     uint32_t cL = C.L, cR = C.R, cP = C.P;
-    asm volatile("" : "+s"(cL), "+s"(cR), "+s"(cP));
+    // the goal / termination constants too (one pin for all, so that the loads go out together): fetched where they are used they
+    // were five serial scalar-load waits on the way to the step's stores; here their latency disappears behind the vector loads'
+    unsigned long long g_reward = __double_as_longlong(C.goal_reward), g_low = __double_as_longlong(C.goal_low_availability),
+                       g_pct = __double_as_longlong(C.goal_own_atleast_percent), g_sla = __double_as_longlong(C.maintain_sla),
+                       g_win = __double_as_longlong(C.winning_reward), g_lose = __double_as_longlong(C.losing_reward);
+    uint32_t g_has = C.has_attacker_goal, g_own = C.goal_own_atleast, g_evict = C.defender_goal_eviction, g_auto = C.auto_reset, g_max = C.max_episode_steps;
+    if (PHASE != 1)
+        asm volatile("" : "+s"(cL), "+s"(cR), "+s"(cP), "+s"(g_reward), "+s"(g_low), "+s"(g_pct), "+s"(g_sla), "+s"(g_win), "+s"(g_lose), "+s"(g_has),
+                          "+s"(g_own), "+s"(g_evict), "+s"(g_auto), "+s"(g_max));
+    else asm volatile("" : "+s"(cL), "+s"(cR), "+s"(cP));
     if (!TOPO_LDS) tb = T.hot;
     if (TOPO_LDS && it == 0u) {                         // cooperative copy of the hot topology image, 16 bytes per lane
         const uint4* src = reinterpret_cast<const uint4*>(T.hot);
@@ -632,19 +641,19 @@ __device__ __forceinline__ void step_body(const DevState& S, const Topo& T, cons
         }
         {
             // goals (env.py:1080-1116) on the state AFTER the defender acted, availability from BEFORE its scan
-            const bool attacker_goal = (C.has_attacker_goal != 0) & !(h1.x < C.goal_reward) & !(ln.owned < C.goal_own_atleast) &
-                                       !((double)ln.owned / (double)S.N < C.goal_own_atleast_percent) &
-                                       !(def_avail && h1.y >= C.goal_low_availability);
-            const bool sla_broken = def_avail && h1.y < C.maintain_sla;
-            const bool evicted = (C.defender_goal_eviction != 0) & (ln.owned == 0);
+            const bool attacker_goal = (g_has != 0) & !(h1.x < __longlong_as_double(g_reward)) & !(ln.owned < g_own) &
+                                       !((double)ln.owned / (double)S.N < __longlong_as_double(g_pct)) &
+                                       !(def_avail && h1.y >= __longlong_as_double(g_low));
+            const bool sla_broken = def_avail && h1.y < __longlong_as_double(g_sla);
+            const bool evicted = (g_evict != 0) & (ln.owned == 0);
             const bool win = attacker_goal | sla_broken;
             const bool play = live & !oob;
             done = play & (win | evicted);
-            const double r_play = win ? C.winning_reward : (evicted ? C.losing_reward : (ln.raw > 0.0 ? ln.raw : 0.0));   // max(0, reward), env.py:1169
+            const double r_play = win ? __longlong_as_double(g_win) : (evicted ? __longlong_as_double(g_lose) : (ln.raw > 0.0 ? ln.raw : 0.0));   // max(0, reward), env.py:1169
             reward = play ? r_play : 0.0;
         }
         h1.x += reward;
-        const bool trunc = live & !done & (C.max_episode_steps != 0) & (step >= C.max_episode_steps);
+        const bool trunc = live & !done & (g_max != 0) & (step >= g_max);
         {
             iok.reward[e] = (float)reward;
             iok.terminated[e] = live ? (done ? 1 : 0) : (uint8_t)((old_flags & F_DONE) ? 1 : 0);
@@ -653,7 +662,7 @@ __device__ __forceinline__ void step_body(const DevState& S, const Topo& T, cons
             if (iok.step_count) iok.step_count[e] = (int32_t)step;
             if (iok.oob) iok.oob[e] = oob ? 1 : 0;
             if (iok.raw_reward) iok.raw_reward[e] = live ? (float)ln.raw : 0.0f;
-            need_reset = (done | trunc) & (C.auto_reset != 0);
+            need_reset = (done | trunc) & (g_auto != 0);
             flags |= (done ? F_DONE : 0u) | (trunc ? F_TRUNC : 0u);
             S.h0[e] = make_uint4(step, flags, ln.n_disc | (ln.n_creds << 16), ln.owned | (ln.dclk << 16));
             S.h1[e] = h1;
