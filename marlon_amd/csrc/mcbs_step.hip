@@ -138,6 +138,11 @@ struct Lane {
     // wide cached-triple set (DevState::cach): this lane's LDS column, [word * wide_stride], staged around a credential leak
     uint64_t* wide_lds = nullptr;
     uint32_t wide_stride = 0;
+    // packed batches, whole step: the env's 4-byte node rows as the step loaded them and the target's row as the attacker left it, so that
+    // re-imaging a node is a pure STORE (a read-modify-write would be a load behind the step's stores: a write-acknowledgement round trip)
+    bool rows_in_regs = false;
+    uint4 prw0 = {0, 0, 0, 0}, prw1 = {0, 0, 0, 0}, prw2 = {0, 0, 0, 0}, prw3 = {0, 0, 0, 0};
+    uint32_t ptgt = 0xFFFFFFFFu, pword = 0;
     const uint8_t* ere_blob = nullptr;   // the topology blob (ExternalRandomEvents reads its cold tables)
 
     __device__ __forceinline__ const HotNode* NS(uint32_t n) const { return reinterpret_cast<const HotNode*>(tb + C.hot_node) + n; }
@@ -387,8 +392,12 @@ struct Lane {
     // reimage_node (actions.py:700-712): agent removed, privilege NoAccess, Imaging for REIMAGING_DURATION ticks; tags,
     // discovered properties and credentials stay (quirk Q6)
     __device__ __forceinline__ void reimage(uint32_t n, uint64_t (&fresh)[WT]) {
-        if (S.packed) reinterpret_cast<uint32_t*>(body + S.off_rows)[n] &= (1u << (S.tiny_p + 4u + S.tiny_v)) - 1u;
-        else row(n)->since = 0;                               // every earlier attack now predates last_reimaging
+        if (S.packed) {                                       // every earlier attack now predates last_reimaging: attacked-since := 0
+            const uint32_t keep = (1u << (S.tiny_p + 4u + S.tiny_v)) - 1u;
+            uint32_t* rw = reinterpret_cast<uint32_t*>(body + S.off_rows) + n;
+            if (rows_in_regs) *rw = (n == ptgt ? pword : dword_of(prw0, prw1, prw2, prw3, n & 15u)) & keep;
+            else *rw &= keep;
+        } else row(n)->since = 0;
         rclear<WT>(m[M_INST], n);
         if (privilege(n)) { set_privilege(n, 0u); owned -= 1; }
         rclear<WT>(m[M_RUN], n);
@@ -596,7 +605,11 @@ __device__ __forceinline__ void step_body(const DevState& S, const Topo& T, cons
         STAMP(3);  // row landed
         ln.template act<!PK, DEFK>(X, skip ? -1.0 : 0.0, kind, src, tgt, X ? (k0 ? a2 : (k1 ? cL + a3 : 0u)) : 0u, (X & k2) ? a3 : 0u, triple);
         // unchanged rows are written back as they were
-        if (PK) reinterpret_cast<uint32_t*>(body + S.off_rows)[tgt] = S.tiny_pack(ln.props, ln.tags, ln.ever, ln.since);
+        if (PK) {
+            const uint32_t w = S.tiny_pack(ln.props, ln.tags, ln.ever, ln.since);
+            reinterpret_cast<uint32_t*>(body + S.off_rows)[tgt] = w;
+            if (PHASE == 0) { ln.rows_in_regs = true; ln.prw0 = rw0; ln.prw1 = rw1; ln.prw2 = rw2; ln.prw3 = rw3; ln.ptgt = tgt; ln.pword = w; }
+        }
         else {
             const uint64_t wpt = ln.props | ((uint64_t)ln.tags << 60);
             *reinterpret_cast<uint4*>(ln.row(tgt)) = make_uint4((uint32_t)wpt, (uint32_t)(wpt >> 32), ln.ever, ln.since);
