@@ -412,6 +412,12 @@ int  mcbs_attacker_wrapper_post(mcbs_batch*, const mcbs_wrapper_buffers* w, floa
 /* ... and the counters of the envs whose dones flag is set back to zero (what the wrapper's reset() does for them). */
 int  mcbs_attacker_wrapper_clear(mcbs_batch*, const mcbs_wrapper_buffers* w, void* stream);
 
+/* dst[e] = src[e] (rows of row_bytes bytes, device arrays of n_envs rows) for the envs whose byte in env_mask is non-zero: the terminal
+ * observation of the envs that just ended — what SB3's DummyVecEnv keeps in infos[i]["terminal_observation"] before it resets an env
+ * (a batched wrapper calls it with mcbs_wrapper_buffers.dones as the mask, then mcbs_reset + mcbs_observe_masked with the same mask: no
+ * host round trip to learn which envs ended). */
+int  mcbs_copy_rows_masked(mcbs_batch*, const void* src, void* dst, size_t row_bytes, const uint8_t* env_mask, void* stream);
+
 /* The reward shaping of marlon's DefenderEnvWrapper.step (defend_wrapper.py:228-282) around mcbs_defender_step, for every env in one
  * launch and in the wrapper's own order of double-precision operations: invalid-action penalty, minus the attacker's last environment
  * reward, loss_reward when availability first drops below maintain_sla (terminating if reset_on_constraint_broken), a penalty

@@ -771,6 +771,15 @@ extern "C" int mcbs_attacker_wrapper_clear(mcbs_batch* b, const mcbs_wrapper_buf
     return launch_ok("wrapper clear");
 }
 
+extern "C" int mcbs_copy_rows_masked(mcbs_batch* b, const void* src, void* dst, size_t row_bytes, const uint8_t* env_mask, void* stream) {
+    if (!b || !src || !dst || !env_mask) return fail(MCBS_EINVAL, "null argument");
+    if (row_bytes == 0) return MCBS_OK;
+    const int vec16 = (reinterpret_cast<uintptr_t>(src) % 16 == 0 && reinterpret_cast<uintptr_t>(dst) % 16 == 0 && row_bytes % 16 == 0) ? 1 : 0;
+    hipLaunchKernelGGL(copy_rows_masked_kernel, dim3((b->S.E + 3) / 4), dim3(256), 0, (hipStream_t)stream, static_cast<const uint8_t*>(src),
+                       static_cast<uint8_t*>(dst), row_bytes, env_mask, b->S.E, vec16);
+    return launch_ok("copy rows");
+}
+
 extern "C" int mcbs_defender_wrapper_post(mcbs_batch* b, const mcbs_defender_wrapper_buffers* w, const mcbs_defender_wrapper_cfg* cfg, void* stream) {
     if (!b || !w || !cfg) return fail(MCBS_EINVAL, "null argument");
     const void* const* p = reinterpret_cast<const void* const*>(w);

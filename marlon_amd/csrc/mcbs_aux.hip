@@ -130,6 +130,24 @@ __global__ __launch_bounds__(256) void wrapper_clear_kernel(uint32_t E, mcbs_wra
     w.timesteps[e] = 0; w.valid_action_count[e] = 0; w.invalid_action_count[e] = 0; w.episode_returns[e] = 0.0; w.has_cyber_reward[e] = 0;
 }
 
+// dst[r] = src[r] for the rows whose mask byte is set: the terminal observation of the envs that just ended (what DummyVecEnv puts in
+// infos[i]["terminal_observation"] before it resets the env), without a host round trip to find out which envs those are.
+// One wavefront per row; 16-byte accesses when rows are 16-byte aligned.
+__global__ __launch_bounds__(256) void copy_rows_masked_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, size_t row_bytes,
+                                                              const uint8_t* __restrict__ mask, uint32_t n_rows, int vec16) {
+    const uint32_t r = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (r >= n_rows || !mask[r]) return;                  // wave-uniform
+    const uint8_t* s = src + (size_t)r * row_bytes;
+    uint8_t* d = dst + (size_t)r * row_bytes;
+    if (vec16) {
+        const size_t nv = row_bytes >> 4;
+        for (size_t i = lane; i < nv; i += 64u) reinterpret_cast<uint4*>(d)[i] = reinterpret_cast<const uint4*>(s)[i];
+        for (size_t i = (nv << 4) + lane; i < row_bytes; i += 64u) d[i] = s[i];
+    } else {
+        for (size_t i = lane; i < row_bytes; i += 64u) d[i] = s[i];
+    }
+}
+
 // DefenderEnvWrapper.step's reward shaping (defend_wrapper.py:228-282), same order of fp64 operations as the host version it replaces
 __global__ __launch_bounds__(256) void defender_wrapper_post_kernel(uint32_t E, mcbs_defender_wrapper_buffers w, mcbs_defender_wrapper_cfg c) {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;

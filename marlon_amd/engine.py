@@ -23,7 +23,7 @@ EXPORTS = [
     "mcbs_last_error", "mcbs_abi_version", "mcbs_topology_create", "mcbs_topology_destroy", "mcbs_batch_create",
     "mcbs_batch_destroy", "mcbs_reset", "mcbs_step", "mcbs_step_observe", "mcbs_observe", "mcbs_observe_masked", "mcbs_action_mask", "mcbs_step_info",
     "mcbs_step_many", "mcbs_rollout_random", "mcbs_attacker_wrapper_post", "mcbs_attacker_wrapper_clear", "mcbs_defender_wrapper_post", "mcbs_sample_actions", "mcbs_decode_attacker_actions", "mcbs_defender_step", "mcbs_defender_observe", "mcbs_set_draw_tape", "mcbs_state_record_bytes", "mcbs_get_state", "mcbs_set_state",
-    "mcbs_timing_enable", "mcbs_timing_read", "mcbs_mask_logits", "mcbs_discrete_action_count",
+    "mcbs_timing_enable", "mcbs_timing_read", "mcbs_mask_logits", "mcbs_discrete_action_count", "mcbs_copy_rows_masked",
 ]
 
 _lib = None
@@ -79,6 +79,7 @@ def load_library(path: Optional[str] = None):
     lib.mcbs_discrete_action_count.restype = C.c_uint64
     lib.mcbs_discrete_action_count.argtypes = [C.c_void_p]
     lib.mcbs_mask_logits.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_size_t, C.c_float, C.c_void_p]
+    lib.mcbs_copy_rows_masked.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     lib.mcbs_timing_enable.argtypes = [C.c_void_p, C.c_int32]
     lib.mcbs_timing_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     for name in EXPORTS:
@@ -243,6 +244,14 @@ class BatchEngine:
     def defender_wrapper_post(self, bufs, cfg) -> None:
         """DefenderEnvWrapper.step's reward shaping for every env in one launch (_abi.DefenderWrapperBuffers / DefenderWrapperCfg)."""
         _check(self.lib, self.lib.mcbs_defender_wrapper_post(self._h, C.byref(bufs), C.byref(cfg), self._stream()), "mcbs_defender_wrapper_post")
+
+    def copy_rows_masked(self, src, dst, env_mask) -> None:
+        """dst[e] = src[e] for the envs whose byte in env_mask (uint8 [E], device) is set; src / dst contiguous [E, ...] of one dtype."""
+        if src.shape != dst.shape or src.dtype != dst.dtype or not (src.is_contiguous() and dst.is_contiguous()) or src.shape[0] != self.E:
+            raise ValueError("copy_rows_masked needs two contiguous [E, ...] tensors of the same shape and dtype")
+        row_bytes = src[0].numel() * src.element_size()
+        _check(self.lib, self.lib.mcbs_copy_rows_masked(self._h, src.data_ptr(), dst.data_ptr(), row_bytes, env_mask.data_ptr(), self._stream()),
+               "mcbs_copy_rows_masked")
 
     def wrapper_clear(self, bufs) -> None:
         _check(self.lib, self.lib.mcbs_attacker_wrapper_clear(self._h, C.byref(bufs), self._stream()), "mcbs_attacker_wrapper_clear")

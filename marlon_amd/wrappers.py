@@ -41,7 +41,8 @@ class AttackerVecEnv:
                  defender_goal=DefenderGoal(eviction=True), defender_constraint=DefenderConstraint(maintain_sla=0.0),
                  winning_reward=5000.0, losing_reward=0.0, max_timesteps: int = 2000, invalid_action_reward_modifier=-1,
                  discrete: bool = False, auto_reset: bool = True, device: Optional[str] = None, seed: int = 0,
-                 env_id_base: int = 0, rng_kind: int = 0, learned_defender: bool = False, materialize_masks: bool = True):
+                 env_id_base: int = 0, rng_kind: int = 0, learned_defender: bool = False, materialize_masks: bool = True,
+                 use_graph: bool = False):
         from .engine import BatchEngine
         self.topo: FlatTopology = initial_environment if isinstance(initial_environment, FlatTopology) else flatten(initial_environment)
         # the wrapper owns truncation and resets (its clock counts invalid actions too), so the engine's own are off
@@ -88,6 +89,15 @@ class AttackerVecEnv:
         self._len_out = t.zeros(n_envs, dtype=t.int32, device=dev)
         self._n_done = t.zeros(1, dtype=t.int32, device=dev)
         self._wb = None
+        # use_graph: the whole wrapper step (decode, environment step + observation, bookkeeping, terminal-observation copy, reset and reset
+        # observation of the envs that ended) is captured into ONE hipGraph on the first call and replayed afterwards: the step has no
+        # host round trip, so what remains on the host is one graph launch.  Outputs are then the wrapper's own buffers (overwritten
+        # by the next step) instead of copies.  Not with a draw tape (its address changes per step).
+        self.use_graph = bool(use_graph)
+        if self.use_graph and rng_kind == 1:
+            raise ValueError("use_graph replays fixed kernel arguments: it cannot be combined with a defender draw tape (rng_kind=TAPE)")
+        self._graph = None
+        self._act_in = t.zeros((n_envs,) if self.discrete else (n_envs, 10), dtype=t.int64, device=dev)
         self.reset()
 
     # -- observation plumbing --
@@ -137,9 +147,8 @@ class AttackerVecEnv:
         self.has_cyber_reward.zero_()
         return self.observation
 
-    def step(self, actions):
-        """-> (observation dict, rewards f32 [E], terminated u8 [E], truncated u8 [E], info dict of tensors)."""
-        t = self.torch
+    def _step_device(self, actions) -> None:
+        """Everything a wrapper step does on the device, enqueued on the current stream without any host round trip."""
         if self.discrete:
             self.engine.decode_attacker_actions(discrete=actions, actions_out=self._rows, invalid_out=self._invalid)
         else:
@@ -154,18 +163,46 @@ class AttackerVecEnv:
                 self.last_cyber_reward, self.has_cyber_reward, self._rewards, self._truncated, self._dones, self._ret_out, self._len_out,
                 self._n_done)])
         self.engine.wrapper_post(self._wb, self.invalid_action_reward_modifier, self.max_timesteps)
+        if self.auto_reset:
+            # what DummyVecEnv.step_wait does for an env that reports done — keep its last observation, reset it, return the reset
+            # observation — for the envs flagged in `dones`, as masked launches (they cost a few microseconds when no env ended):
+            for k in self._obs:
+                self.engine.copy_rows_masked(self._obs[k], self._terminal[k], self._dones)
+            self.engine.reset(self._dones)
+            self.engine.observe(self._obs, env_mask=self._dones)   # the others keep their observation
+            self.engine.wrapper_clear(self._wb)
+
+    def step(self, actions):
+        """-> (observation dict, rewards f32 [E], terminated u8 [E], truncated u8 [E], info dict of tensors)."""
+        t = self.torch
+        if self.use_graph:
+            a = actions if isinstance(actions, t.Tensor) else t.as_tensor(np.asarray(actions))
+            self._act_in.copy_(a.to(device=self.engine.device).reshape(self._act_in.shape), non_blocking=True)
+            if self._graph is None:
+                self._step_device(self._act_in)            # this step runs eagerly (it also creates the argument blocks) ...
+                t.cuda.synchronize(self.engine.device)
+                g = t.cuda.CUDAGraph()
+                side = t.cuda.Stream(device=self.engine.device)
+                side.wait_stream(t.cuda.current_stream(self.engine.device))
+                with t.cuda.stream(side):
+                    with t.cuda.graph(g, stream=side):
+                        self._step_device(self._act_in)
+                t.cuda.current_stream(self.engine.device).wait_stream(side)
+                self._graph = g
+                # ... and is then captured for the steps to come (capturing executes nothing)
+            else:
+                self._graph.replay()
+            invalid = self._invalid.view(t.bool)
+            info = {"invalid_action": invalid, "cyber_step_executed": ~invalid,
+                    "network_availability": self.engine.info["network_availability"], "step_count": self.engine.info["step_count"],
+                    "episode_return": self._ret_out, "episode_length": self._len_out}
+            return self.observation, self._rewards, self.engine.terminated, self._truncated, info
+        self._step_device(actions)
         invalid = self._invalid.view(t.bool)
-        rewards, truncated, terminated = self._rewards.clone(), self._truncated.clone(), terminated.clone()
+        rewards, truncated, terminated = self._rewards.clone(), self._truncated.clone(), self.engine.terminated.clone()
         info = {"invalid_action": invalid.clone(), "cyber_step_executed": ~invalid,
                 "network_availability": self.engine.info["network_availability"], "step_count": self.engine.info["step_count"],
                 "episode_return": self._ret_out.clone(), "episode_length": self._len_out.clone()}
-        if self.auto_reset and int(self._n_done.item()):      # (one host sync per step)
-            ended = self._dones.nonzero().squeeze(1)
-            for k in self._obs:                       # terminal observation of the envs that ended only, not the whole batch
-                self._terminal[k].index_copy_(0, ended, self._obs[k].index_select(0, ended))
-            self.engine.reset(self._dones)
-            self.engine.observe(self._obs, env_mask=self._dones)   # reset observation for the envs that ended; the others keep theirs
-            self.engine.wrapper_clear(self._wb)
         return self.observation, rewards, terminated, truncated, info
 
     def close(self) -> None:

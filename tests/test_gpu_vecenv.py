@@ -142,3 +142,48 @@ def test_vecenv_batch_matches_the_wrapper_it_adapts():
     assert episodes >= E                                                 # every env ended (win or truncation at 30) at least once
     assert a.get_attr("timesteps", indices=[0, 5]) == [int(length[0]), int(length[5])]
     a.close(); raw.close(); dev_env.close()
+
+
+def test_graph_replayed_wrapper_step_equals_eager():
+    """AttackerVecEnv(use_graph=True): the whole wrapper step as one hipGraph replay (no host round trip) returns what the eager
+    wrapper returns — rewards, flags, infos, observations, terminal observations, episode statistics — over episodes that end and
+    reset inside the graph; with and without materialised masks; with an in-env defender (Philox)."""
+    import torch
+    from marlon_amd import cyberbattle_env as ce
+    from marlon_amd.wrappers import AttackerVecEnv
+    E = 1024
+    for lean in (False, True):
+        kw = dict(maximum_node_count=12, maximum_total_credentials=10, attacker_goal=ce.AttackerGoal(own_atleast=6),
+                  defender_agent=ce.ScanAndReimageCompromisedMachines(0.6, 2, 5), defender_constraint=ce.DefenderConstraint(0.8),
+                  max_timesteps=20, discrete=True, seed=5, materialize_masks=not lean)
+        eager = AttackerVecEnv(parity.topology_for("toyctf"), E, **kw)
+        graph = AttackerVecEnv(parity.topology_for("toyctf"), E, use_graph=True, **kw)
+        ref = eager if not lean else AttackerVecEnv(parity.topology_for("toyctf"), E, **dict(kw, materialize_masks=True))
+        g = torch.Generator(device=eager.engine.device).manual_seed(11)
+        ended = 0
+        for t in range(70):
+            m = ref.action_masks()
+            scores = torch.rand(m.shape, generator=g, device=m.device)
+            actions = torch.where(m, scores, torch.full_like(scores, -1.0)).argmax(dim=1)
+            if t % 6 == 2:
+                actions[::9] = eager.discrete_n - 1
+            o1, r1, te1, tr1, i1 = eager.step(actions)
+            o2, r2, te2, tr2, i2 = graph.step(actions)
+            if lean:
+                ref.step(actions)
+            assert torch.equal(r1, r2) and torch.equal(te1, te2) and torch.equal(tr1, tr2), f"lean={lean} step {t}"
+            for k in ("invalid_action", "network_availability", "step_count", "episode_return", "episode_length"):
+                assert torch.equal(i1[k], i2[k]), f"lean={lean} step {t} info {k}"
+            for k in o1:
+                assert torch.equal(o1[k], o2[k]), f"lean={lean} step {t} obs {k}"
+            d = ((te1 | tr1) != 0)
+            if bool(d.any()):
+                for k in eager.terminal_observation:
+                    assert torch.equal(eager.terminal_observation[k][d], graph.terminal_observation[k][d]), f"lean={lean} step {t} terminal {k}"
+                ended += int(d.sum())
+        assert ended >= E
+        eager.close(); graph.close()
+        if lean:
+            ref.close()
+    with pytest.raises(ValueError, match="draw tape"):
+        AttackerVecEnv(parity.topology_for("toyctf"), 4, maximum_node_count=12, maximum_total_credentials=10, use_graph=True, rng_kind=1)

@@ -13,9 +13,9 @@ from marlon_amd.samples import chainpattern, toy_ctf  # noqa: E402
 
 for name, env, E, kw in (("chain10", chainpattern.new_environment(10), 65536, dict(maximum_node_count=12, maximum_total_credentials=12)),
                          ("toyctf", toy_ctf.new_environment(), 16384, dict(maximum_node_count=12, maximum_total_credentials=10))):
-    for discrete, lean in ((False, False), (True, False), (True, True)):
+    for discrete, lean, graph in ((False, False, False), (True, False, False), (True, True, False), (True, False, True), (True, True, True)):
         # lean: no action mask is materialised; the policy's logits are masked in place by mcbs_mask_logits (timed separately below)
-        venv = AttackerVecEnv(env, E, discrete=discrete, materialize_masks=not lean, **kw)
+        venv = AttackerVecEnv(env, E, discrete=discrete, materialize_masks=not lean, use_graph=graph, **kw)
         ref = AttackerVecEnv(env, E, discrete=True, **kw) if lean else None      # supplies the masks the random policy samples from
         venv.reset()
         g = torch.Generator(device=venv.engine.device)
@@ -53,7 +53,7 @@ for name, env, E, kw in (("chain10", chainpattern.new_environment(10), 65536, di
             venv.action_masks() if (discrete and not lean) else None
         torch.cuda.synchronize()
         dm = (time.perf_counter() - t0) / K
-        row = dict(topology=name, envs=E, discrete=discrete, masks_materialised=not lean, step_us=dt * 1e6, action_masks_us=dm * 1e6,
+        row = dict(topology=name, envs=E, discrete=discrete, masks_materialised=not lean, graph=graph, step_us=dt * 1e6, action_masks_us=dm * 1e6,
                    M_env_steps_per_s=E / dt / 1e6)
         if lean:
             for dtype in (torch.float32, torch.bfloat16):
