@@ -412,11 +412,18 @@ int  mcbs_attacker_wrapper_post(mcbs_batch*, const mcbs_wrapper_buffers* w, floa
 /* ... and the counters of the envs whose dones flag is set back to zero (what the wrapper's reset() does for them). */
 int  mcbs_attacker_wrapper_clear(mcbs_batch*, const mcbs_wrapper_buffers* w, void* stream);
 
-/* dst[e] = src[e] (rows of row_bytes bytes, device arrays of n_envs rows) for the envs whose byte in env_mask is non-zero: the terminal
- * observation of the envs that just ended — what SB3's DummyVecEnv keeps in infos[i]["terminal_observation"] before it resets an env
- * (a batched wrapper calls it with mcbs_wrapper_buffers.dones as the mask, then mcbs_reset + mcbs_observe_masked with the same mask: no
- * host round trip to learn which envs ended). */
-int  mcbs_copy_rows_masked(mcbs_batch*, const void* src, void* dst, size_t row_bytes, const uint8_t* env_mask, void* stream);
+/* dst[i][e] = src[i][e] (rows of row_bytes[i] bytes, device arrays of n_envs rows) for the envs whose byte in env_mask is non-zero and up to
+ * eight arrays in one launch: the terminal observation of the envs that just ended — what SB3's DummyVecEnv keeps in
+ * infos[i]["terminal_observation"] before it resets an env.  A batched wrapper calls it with mcbs_wrapper_buffers.dones as the mask, then
+ * mcbs_reset + mcbs_observe_masked with the same mask: no host round trip to learn which envs ended.  Like those two it scans the mask
+ * 64 envs per wavefront, so it costs a few microseconds when no env ended. */
+typedef struct mcbs_row_copies {
+    uint32_t n, pad;
+    const void* src[8];
+    void*       dst[8];
+    size_t      row_bytes[8];
+} mcbs_row_copies;
+int  mcbs_copy_rows_masked(mcbs_batch*, const mcbs_row_copies* copies, const uint8_t* env_mask, void* stream);
 
 /* The reward shaping of marlon's DefenderEnvWrapper.step (defend_wrapper.py:228-282) around mcbs_defender_step, for every env in one
  * launch and in the wrapper's own order of double-precision operations: invalid-action penalty, minus the attacker's last environment

@@ -163,3 +163,8 @@ class EnvSpec:
         c.seed = int(self.seed) & (2 ** 64 - 1)
         c.env_id_base = int(self.env_id_base)
         return c
+
+
+class RowCopies(C.Structure):
+    """mcbs_row_copies (include/mcbs.h): up to eight (src, dst, row_bytes) triples for mcbs_copy_rows_masked."""
+    _fields_ = [("n", C.c_uint32), ("pad", C.c_uint32), ("src", C.c_void_p * 8), ("dst", C.c_void_p * 8), ("row_bytes", C.c_size_t * 8)]

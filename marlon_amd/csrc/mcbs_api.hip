@@ -651,8 +651,13 @@ static int launch_obs(mcbs_batch* b, const mcbs_obs_buffers* o, hipStream_t st, 
     }
     O.fuse_discrete = dwords_ok && o->mask_discrete && ML % 4 == 0 && MR % 4 == 0 && b->C.L > 0 && b->C.R > 0 &&
                       reinterpret_cast<uintptr_t>(o->mask_discrete) % 4 == 0;
-    hipLaunchKernelGGL(obs_small_kernel, dim3((b->S.E + 3) / 4), dim3(256), 4u * obs_stage_bytes(b->S.N, b->topo->H()->n_triples), st,
-                       b->S, b->T, b->C_dev, O, b->digest);
+    const uint32_t obs_shm = 4u * obs_stage_bytes(b->S.N, b->topo->H()->n_triples);
+    if (env_mask) {     // sparse by nature (the envs a VecEnv just reset): 64 envs' mask bytes per wavefront
+        const uint32_t waves = (b->S.E + 63u) / 64u;
+        hipLaunchKernelGGL(obs_scan_kernel, dim3((waves + 3u) / 4u), dim3(256), obs_shm, st, b->S, b->T, b->C_dev, O, b->digest);
+    } else {
+        hipLaunchKernelGGL(obs_small_kernel, dim3((b->S.E + 3) / 4), dim3(256), obs_shm, st, b->S, b->T, b->C_dev, O, b->digest);
+    }
     int rc = launch_ok("obs_small");
     if (rc) return rc;
     mcbs_obs_buffers rest = *o;                // what the fused wavefront has not written
@@ -771,12 +776,13 @@ extern "C" int mcbs_attacker_wrapper_clear(mcbs_batch* b, const mcbs_wrapper_buf
     return launch_ok("wrapper clear");
 }
 
-extern "C" int mcbs_copy_rows_masked(mcbs_batch* b, const void* src, void* dst, size_t row_bytes, const uint8_t* env_mask, void* stream) {
-    if (!b || !src || !dst || !env_mask) return fail(MCBS_EINVAL, "null argument");
-    if (row_bytes == 0) return MCBS_OK;
-    const int vec16 = (reinterpret_cast<uintptr_t>(src) % 16 == 0 && reinterpret_cast<uintptr_t>(dst) % 16 == 0 && row_bytes % 16 == 0) ? 1 : 0;
-    hipLaunchKernelGGL(copy_rows_masked_kernel, dim3((b->S.E + 3) / 4), dim3(256), 0, (hipStream_t)stream, static_cast<const uint8_t*>(src),
-                       static_cast<uint8_t*>(dst), row_bytes, env_mask, b->S.E, vec16);
+extern "C" int mcbs_copy_rows_masked(mcbs_batch* b, const mcbs_row_copies* copies, const uint8_t* env_mask, void* stream) {
+    if (!b || !copies || !env_mask) return fail(MCBS_EINVAL, "null argument");
+    if (copies->n == 0) return MCBS_OK;
+    if (copies->n > 8) return fail(MCBS_EINVAL, "at most eight arrays per call");
+    for (uint32_t i = 0; i < copies->n; ++i) if (!copies->src[i] || !copies->dst[i]) return fail(MCBS_EINVAL, "null array");
+    const uint32_t waves = (b->S.E + 63u) / 64u;
+    hipLaunchKernelGGL(copy_rows_masked_kernel, dim3((waves + 3u) / 4u), dim3(256), 0, (hipStream_t)stream, *copies, env_mask, b->S.E);
     return launch_ok("copy rows");
 }
 

@@ -130,21 +130,29 @@ __global__ __launch_bounds__(256) void wrapper_clear_kernel(uint32_t E, mcbs_wra
     w.timesteps[e] = 0; w.valid_action_count[e] = 0; w.invalid_action_count[e] = 0; w.episode_returns[e] = 0.0; w.has_cyber_reward[e] = 0;
 }
 
-// dst[r] = src[r] for the rows whose mask byte is set: the terminal observation of the envs that just ended (what DummyVecEnv puts in
-// infos[i]["terminal_observation"] before it resets the env), without a host round trip to find out which envs those are.
-// One wavefront per row; 16-byte accesses when rows are 16-byte aligned.
-__global__ __launch_bounds__(256) void copy_rows_masked_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, size_t row_bytes,
-                                                              const uint8_t* __restrict__ mask, uint32_t n_rows, int vec16) {
-    const uint32_t r = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
-    if (r >= n_rows || !mask[r]) return;                  // wave-uniform
-    const uint8_t* s = src + (size_t)r * row_bytes;
-    uint8_t* d = dst + (size_t)r * row_bytes;
-    if (vec16) {
-        const size_t nv = row_bytes >> 4;
-        for (size_t i = lane; i < nv; i += 64u) reinterpret_cast<uint4*>(d)[i] = reinterpret_cast<const uint4*>(s)[i];
-        for (size_t i = (nv << 4) + lane; i < row_bytes; i += 64u) d[i] = s[i];
-    } else {
-        for (size_t i = lane; i < row_bytes; i += 64u) d[i] = s[i];
+// dst[i][r] = src[i][r] for the rows whose mask byte is set: the terminal observation of the envs that just ended (what DummyVecEnv puts
+// in infos[i]["terminal_observation"] before it resets the env), without a host round trip to find out which envs those are.
+// A wavefront SCANS 64 rows' mask bytes (one coalesced load + ballot) and copies the flagged rows one after the other with all 64
+// lanes (16-byte accesses when aligned): E / 64 wavefronts in all, so the launch costs next to nothing when no env ended.
+__global__ __launch_bounds__(256) void copy_rows_masked_kernel(mcbs_row_copies rc, const uint8_t* __restrict__ mask, uint32_t n_rows) {
+    const uint32_t r0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * 64u, lane = threadIdx.x & 63u;
+    if (r0 >= n_rows) return;
+    uint64_t m = __ballot(r0 + lane < n_rows && mask[r0 + lane] != 0);
+    while (m) {
+        const uint32_t r = r0 + (uint32_t)__builtin_ctzll(m);
+        m &= m - 1;
+        for (uint32_t f = 0; f < rc.n; ++f) {
+            const size_t nb = rc.row_bytes[f];
+            const uint8_t* s = static_cast<const uint8_t*>(rc.src[f]) + (size_t)r * nb;
+            uint8_t* d = static_cast<uint8_t*>(rc.dst[f]) + (size_t)r * nb;
+            if (((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(d)) & 15u) == 0) {
+                const size_t nv = nb >> 4;
+                for (size_t i = lane; i < nv; i += 64u) reinterpret_cast<uint4*>(d)[i] = reinterpret_cast<const uint4*>(s)[i];
+                for (size_t i = (nv << 4) + lane; i < nb; i += 64u) d[i] = s[i];
+            } else {
+                for (size_t i = lane; i < nb; i += 64u) d[i] = s[i];
+            }
+        }
     }
 }
 

@@ -61,15 +61,9 @@ __device__ __forceinline__ ObsStage obs_stage_at(uint8_t* base, uint32_t n_nodes
 // everything about discovered node i and lane r everything about cached credential r in one burst (three dependent levels:
 // header; the two lists; rows / static tables), parks it in LDS by external index, and the rest of the kernel only computes
 // from LDS and streams stores.
-__global__ __launch_bounds__(256) void obs_small_kernel(DevState S, Topo T, const StepCfg* __restrict__ Cp, ObsIO O, ObsDigest* digest) {
-    const StepCfg& C = *Cp;   // device copy: by value it would push the arguments past 256 bytes (profiles/round1_notes.md)
-    extern __shared__ uint4 obs_lds[];
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;   // wave index as a scalar
-    const uint32_t e = blockIdx.x * 4u + wave;
-    if (e >= S.E) return;                     // whole wavefront leaves together
-    if (O.env_mask && !O.env_mask[e]) return; // wave-uniform: one wavefront per env
-    const uint32_t n_triples_all = T.H().n_triples;
-    const ObsStage st = obs_stage_at(reinterpret_cast<uint8_t*>(obs_lds) + wave * obs_stage_bytes(S.N, n_triples_all), S.N, n_triples_all);
+// The observation of ONE env by one wavefront (e wave-uniform, st = the wavefront's staging area in LDS).
+__device__ __forceinline__ void obs_env(const DevState& S, const Topo& T, const StepCfg& C, const ObsIO& O, ObsDigest* digest, const uint32_t e,
+                                        const uint32_t lane, const ObsStage& st) {
     const uint4 h0 = S.h0[e];
     const uint32_t flags = h0.y, n_disc = h0.z & 0xFFFFu, n_creds = h0.z >> 16;
     if (!O.masks_only && (flags & F_SKIP)) return;   // split step, skip action: the env's previous observation stands
@@ -364,6 +358,40 @@ __global__ __launch_bounds__(256) void obs_small_kernel(DevState S, Topo T, cons
             out[i0 >> 2] = v;
         }
         }
+    }
+}
+
+// One wavefront per env (every env, or the env's byte in env_mask decides: callers with sparse masks use obs_scan_kernel instead).
+__global__ __launch_bounds__(256) void obs_small_kernel(DevState S, Topo T, const StepCfg* __restrict__ Cp, ObsIO O, ObsDigest* digest) {
+    const StepCfg& C = *Cp;   // device copy: by value it would push the arguments past 256 bytes (profiles/round1_notes.md)
+    extern __shared__ uint4 obs_lds[];
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;   // wave index as a scalar
+    const uint32_t e = blockIdx.x * 4u + wave;
+    if (e >= S.E) return;                     // whole wavefront leaves together
+    if (O.env_mask && !O.env_mask[e]) return; // wave-uniform: one wavefront per env
+    const uint32_t n_triples_all = T.H().n_triples;
+    const ObsStage st = obs_stage_at(reinterpret_cast<uint8_t*>(obs_lds) + wave * obs_stage_bytes(S.N, n_triples_all), S.N, n_triples_all);
+    obs_env(S, T, C, O, digest, e, lane, st);
+}
+
+// mcbs_observe_masked (the reset observation of the envs a VecEnv just reset): a wavefront scans the mask bytes of 64 envs (one
+// coalesced load + ballot) and writes the flagged envs' observations one after the other — E / 64 wavefronts in all, so the launch
+// costs a few microseconds when no env was reset, instead of E wavefronts that each look at one byte and leave.
+__global__ __launch_bounds__(256) void obs_scan_kernel(DevState S, Topo T, const StepCfg* __restrict__ Cp, ObsIO O, ObsDigest* digest) {
+    const StepCfg& C = *Cp;
+    extern __shared__ uint4 obs_lds[];
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    const uint32_t e0 = (blockIdx.x * 4u + wave) * 64u;
+    if (e0 >= S.E) return;
+    const uint32_t n_triples_all = T.H().n_triples;
+    const ObsStage st = obs_stage_at(reinterpret_cast<uint8_t*>(obs_lds) + wave * obs_stage_bytes(S.N, n_triples_all), S.N, n_triples_all);
+    uint64_t m = __ballot(e0 + lane < S.E && O.env_mask[e0 + lane] != 0);
+    while (m) {
+        const uint32_t e = e0 + (uint32_t)__builtin_ctzll(m);
+        m &= m - 1;
+        obs_env(S, T, C, O, digest, e, lane, st);
+        __builtin_amdgcn_wave_barrier();      // the next env reuses the staging area
+        __threadfence_block();
     }
 }
 

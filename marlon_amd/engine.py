@@ -79,7 +79,7 @@ def load_library(path: Optional[str] = None):
     lib.mcbs_discrete_action_count.restype = C.c_uint64
     lib.mcbs_discrete_action_count.argtypes = [C.c_void_p]
     lib.mcbs_mask_logits.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_size_t, C.c_float, C.c_void_p]
-    lib.mcbs_copy_rows_masked.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    lib.mcbs_copy_rows_masked.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.mcbs_timing_enable.argtypes = [C.c_void_p, C.c_int32]
     lib.mcbs_timing_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     for name in EXPORTS:
@@ -245,13 +245,19 @@ class BatchEngine:
         """DefenderEnvWrapper.step's reward shaping for every env in one launch (_abi.DefenderWrapperBuffers / DefenderWrapperCfg)."""
         _check(self.lib, self.lib.mcbs_defender_wrapper_post(self._h, C.byref(bufs), C.byref(cfg), self._stream()), "mcbs_defender_wrapper_post")
 
-    def copy_rows_masked(self, src, dst, env_mask) -> None:
-        """dst[e] = src[e] for the envs whose byte in env_mask (uint8 [E], device) is set; src / dst contiguous [E, ...] of one dtype."""
-        if src.shape != dst.shape or src.dtype != dst.dtype or not (src.is_contiguous() and dst.is_contiguous()) or src.shape[0] != self.E:
-            raise ValueError("copy_rows_masked needs two contiguous [E, ...] tensors of the same shape and dtype")
-        row_bytes = src[0].numel() * src.element_size()
-        _check(self.lib, self.lib.mcbs_copy_rows_masked(self._h, src.data_ptr(), dst.data_ptr(), row_bytes, env_mask.data_ptr(), self._stream()),
-               "mcbs_copy_rows_masked")
+    def copy_rows_masked(self, pairs, env_mask) -> None:
+        """dst[e] = src[e] for the envs whose byte in env_mask (uint8 [E], device) is set, for up to eight (src, dst) pairs of
+        contiguous [E, ...] tensors in one launch."""
+        from ._abi import RowCopies
+        if not 0 < len(pairs) <= 8:
+            raise ValueError("copy_rows_masked takes one to eight (src, dst) pairs")
+        rc = RowCopies()
+        rc.n = len(pairs)
+        for i, (src, dst) in enumerate(pairs):
+            if src.shape != dst.shape or src.dtype != dst.dtype or not (src.is_contiguous() and dst.is_contiguous()) or src.shape[0] != self.E:
+                raise ValueError("copy_rows_masked needs contiguous [E, ...] tensors of the same shape and dtype")
+            rc.src[i], rc.dst[i], rc.row_bytes[i] = src.data_ptr(), dst.data_ptr(), src[0].numel() * src.element_size()
+        _check(self.lib, self.lib.mcbs_copy_rows_masked(self._h, C.byref(rc), env_mask.data_ptr(), self._stream()), "mcbs_copy_rows_masked")
 
     def wrapper_clear(self, bufs) -> None:
         _check(self.lib, self.lib.mcbs_attacker_wrapper_clear(self._h, C.byref(bufs), self._stream()), "mcbs_attacker_wrapper_clear")

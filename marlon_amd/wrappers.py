@@ -163,11 +163,11 @@ class AttackerVecEnv:
                 self.last_cyber_reward, self.has_cyber_reward, self._rewards, self._truncated, self._dones, self._ret_out, self._len_out,
                 self._n_done)])
         self.engine.wrapper_post(self._wb, self.invalid_action_reward_modifier, self.max_timesteps)
-        if self.auto_reset:
-            # what DummyVecEnv.step_wait does for an env that reports done — keep its last observation, reset it, return the reset
-            # observation — for the envs flagged in `dones`, as masked launches (they cost a few microseconds when no env ended):
-            for k in self._obs:
-                self.engine.copy_rows_masked(self._obs[k], self._terminal[k], self._dones)
+        # what DummyVecEnv.step_wait does for an env that reports done — keep its last observation, reset it, return the reset
+        # observation — for the envs flagged in `dones`, as mask-scanning launches (a few microseconds when no env ended).  Eagerly,
+        # one host read of the done counter skips them on the (common) steps where nothing ended; a captured step always carries them.
+        if self.auto_reset and (self.use_graph or int(self._n_done.item())):
+            self.engine.copy_rows_masked([(self._obs[k], self._terminal[k]) for k in self._obs], self._dones)
             self.engine.reset(self._dones)
             self.engine.observe(self._obs, env_mask=self._dones)   # the others keep their observation
             self.engine.wrapper_clear(self._wb)
