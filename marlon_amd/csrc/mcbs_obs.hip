@@ -64,7 +64,17 @@ __device__ __forceinline__ ObsStage obs_stage_at(uint8_t* base, uint32_t n_nodes
 // The observation of ONE env by one wavefront (e wave-uniform, st = the wavefront's staging area in LDS).
 __device__ __forceinline__ void obs_env(const DevState& S, const Topo& T, const StepCfg& C, const ObsIO& O, ObsDigest* digest, const uint32_t e,
                                         const uint32_t lane, const ObsStage& st) {
+    // level 1: everything whose address depends on the env index only goes out with the header — entry `lane` of both lists (clamped to
+    // the list; meaningful only below the counts the header brings) and, for up to 64 nodes, the one word of the three node sets the
+    // observation reads.  The rows / static tables those entries point at are level 2: two dependent round trips per wavefront, not three.
+    const uint8_t* body_l1 = S.body + (size_t)e * S.body_stride;
+    const uint32_t n_trip_cap = T.H().n_triples;                       // the credential list holds up to n_triples entries (+ one slack slot)
     const uint4 h0 = S.h0[e];
+    const uint32_t dl_head = body_l1[S.off_disc + (lane < S.N ? lane : S.N - 1u)];
+    const uint32_t cl_head = reinterpret_cast<const uint16_t*>(body_l1 + S.off_cred)[lane < n_trip_cap ? lane : n_trip_cap];
+    const bool one_word = S.NW == 1u;
+    uint64_t w_inst = 0, w_plo = 0, w_phi = 0;
+    if (one_word) { w_inst = S.get(M_INST, 0, e); w_plo = S.get(M_PLO, 0, e); w_phi = S.get(M_PHI, 0, e); }
     const uint32_t flags = h0.y, n_disc = h0.z & 0xFFFFu, n_creds = h0.z >> 16;
     if (!O.masks_only && (flags & F_SKIP)) return;   // split step, skip action: the env's previous observation stands
     const bool blank = !O.masks_only && (flags & F_OOB) != 0;
@@ -78,6 +88,7 @@ __device__ __forceinline__ void obs_env(const DevState& S, const Topo& T, const 
     const uint32_t Nm = O.Nmax, NP = C.n_props, L = C.L;
 
     // ---------------- loads ----------------
+    // (the list heads were fetched with the header, before the counts were known: see the top of this function)
     uint64_t own_ext[4] = {0, 0, 0, 0};
 #pragma unroll
     for (uint32_t c = 0; c < 4; ++c) {
@@ -85,18 +96,19 @@ __device__ __forceinline__ void obs_env(const DevState& S, const Topo& T, const 
         if (c * 64u < n_disc) {               // wave-uniform
             bool own = false;
             if (i < n_disc) {
-                const uint32_t n = dl[i];
-                own = S.has(M_INST, n, e);
+                const uint32_t n = c == 0 ? dl_head : dl[i];
+                own = one_word ? (bool)((w_inst >> n) & 1ull) : S.has(M_INST, n, e);
                 st.ext_of[n] = (uint8_t)i;
                 st.props[i] = S.row_get(body, n).props_tags & ROW_PROPS_MASK;
                 st.lmask[i] = local_mask_of(C, NS, body, n);
-                st.priv[i] = (uint8_t)((uint32_t)S.has(M_PLO, n, e) | ((uint32_t)S.has(M_PHI, n, e) << 1));
+                st.priv[i] = one_word ? (uint8_t)(((w_plo >> n) & 1ull) | (((w_phi >> n) & 1ull) << 1))
+                                      : (uint8_t)((uint32_t)S.has(M_PLO, n, e) | ((uint32_t)S.has(M_PHI, n, e) << 1));
             }
             own_ext[c] = __ballot(own);
         }
     }
     for (uint32_t i = lane; i < n_creds; i += 64u) {
-        const mcbs_triple t = TR[cl[i]];
+        const mcbs_triple t = TR[i < 64u ? cl_head : cl[i]];
         st.cred_node[i] = (uint8_t)t.node;
         st.cred_port[i] = (uint8_t)t.port;
     }
