@@ -652,6 +652,13 @@ static int launch_obs(mcbs_batch* b, const mcbs_obs_buffers* o, hipStream_t st, 
     O.fuse_discrete = dwords_ok && o->mask_discrete && ML % 4 == 0 && MR % 4 == 0 && b->C.L > 0 && b->C.R > 0 &&
                       reinterpret_cast<uintptr_t>(o->mask_discrete) % 4 == 0;
     const uint32_t obs_shm = 4u * obs_stage_bytes(b->S.N, b->topo->H()->n_triples);
+    const bool no_masks = !o->mask_local && !o->mask_remote && !o->mask_connect && !o->mask_discrete;
+    if (!env_mask && !masks_only && no_masks && b->S.NW == 1u && b->S.N <= 16u && O.Nmax <= 16u && O.Cmax <= 16u && b->topo->H()->n_triples <= 15u &&
+        b->cfg.defender_kind != MCBS_DEFENDER_RANDOM_EVENTS && !b->no_fused_masks) {
+        // ~1 KB per env, no mask field: sixteen lanes per env instead of a wavefront (mcbs_obs.hip obs_tiny_kernel)
+        hipLaunchKernelGGL(obs_tiny_kernel, dim3((b->S.E + 15u) / 16u), dim3(256), 0, st, b->S, b->T, b->C_dev, O, b->digest);
+        return launch_ok("obs_tiny");
+    }
     if (env_mask) {     // sparse by nature (the envs a VecEnv just reset): 64 envs' mask bytes per wavefront
         const uint32_t waves = (b->S.E + 63u) / 64u;
         hipLaunchKernelGGL(obs_scan_kernel, dim3((waves + 3u) / 4u), dim3(256), obs_shm, st, b->S, b->T, b->C_dev, O, b->digest);

@@ -373,6 +373,112 @@ __device__ __forceinline__ void obs_env(const DevState& S, const Topo& T, const 
     }
 }
 
+// Small topologies, no mask field requested (a policy that applies the action mask to its logits with mcbs_mask_logits): the observation
+// is ~1 KB per env and a wavefront per env spends its life waiting on two dependent loads for 64 B-sized jobs — the launch is bound by
+// wavefront turnover (45 us for 65 536 Chain-10 envs).  Here SIXTEEN LANES serve an env (four envs per wavefront): lane j fetches
+// everything about discovered node j and cached credential j, the 16-lane group stages it in its own 192 bytes of LDS, and streams the
+// fields out.  Same values as obs_env, field by field (tests/test_gpu_vecenv.py, test_gpu_logits.py).  Needs at most 16 nodes / cached
+// credentials per env and a single set word (NW == 1).
+struct TinyStage { uint64_t props[16]; uint8_t priv[16], ext_of[16], cred_ext[16], cred_port[16]; };   // 192 bytes per env
+static_assert(sizeof(TinyStage) == 192, "tiny stage");
+
+__global__ __launch_bounds__(256) void obs_tiny_kernel(DevState S, Topo T, const StepCfg* __restrict__ Cp, ObsIO O, ObsDigest* digest) {
+    const StepCfg& C = *Cp;
+    __shared__ TinyStage stage[16];
+    const uint32_t grp = threadIdx.x >> 4, j = threadIdx.x & 15u, lane = threadIdx.x & 63u;
+    const uint32_t e = blockIdx.x * 16u + grp;
+    const bool valid = e < S.E;
+    const uint32_t ec = valid ? e : 0u;
+    TinyStage& st = stage[grp];
+    const uint8_t* body = S.body + (size_t)ec * S.body_stride;
+    const uint32_t n_trip_cap = T.H().n_triples;
+    // level 1
+    const uint4 h0 = S.h0[ec];
+    const uint32_t n = body[S.off_disc + (j < S.N ? j : S.N - 1u)];
+    const uint32_t tid = reinterpret_cast<const uint16_t*>(body + S.off_cred)[j < n_trip_cap ? j : n_trip_cap];
+    const uint64_t w_inst = S.get(M_INST, 0, ec), w_plo = S.get(M_PLO, 0, ec), w_phi = S.get(M_PHI, 0, ec);
+    const uint32_t flags = h0.y, n_disc = h0.z & 0xFFFFu, n_creds = h0.z >> 16;
+    const bool live = valid && !(flags & F_SKIP);             // split step, skip action: the env's previous observation stands
+    const bool blank = (flags & F_OOB) != 0;
+    const uint32_t kind = (flags >> F_KIND_SHIFT) & 0xFu, level = (flags >> F_LEVEL_SHIFT) & 3u;
+    const uint32_t new_nodes = (flags >> F_NEWNODES_SHIFT) & 0x3FFu, new_creds = (flags >> F_NEWCREDS_SHIFT) & 0x3FFu;
+    // level 2
+    const mcbs_triple* TR = reinterpret_cast<const mcbs_triple*>(T.base + C.off_triple);
+    const bool is_node = j < n_disc, is_cred = j < n_creds;
+    const uint64_t props = S.row_get(body, n).props_tags & ROW_PROPS_MASK;
+    const mcbs_triple tr = TR[is_cred ? tid : 0u];
+    const bool own = is_node && ((w_inst >> n) & 1ull);
+    const uint32_t own16 = (uint32_t)(__ballot(own) >> (lane & 48u)) & 0xFFFFu;      // this env's owned-source bits by external index
+    if (is_node) {
+        st.ext_of[n & 15u] = (uint8_t)j;
+        st.props[j] = props;
+        st.priv[j] = (uint8_t)(((w_plo >> n) & 1ull) | (((w_phi >> n) & 1ull) << 1));
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    if (is_cred) { st.cred_ext[j] = st.ext_of[tr.node & 15u]; st.cred_port[j] = (uint8_t)tr.port; }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    if (!live) return;                                         // (after the wave-level operations: the four envs of a wavefront differ)
+    // ---------------- stores ----------------
+    if (j == 0) {
+        ObsDigest d;
+        d.own_ext[0] = blank ? 0ull : (uint64_t)own16; d.own_ext[1] = d.own_ext[2] = d.own_ext[3] = 0ull;
+        d.n_disc = n_disc; d.n_creds = n_creds; d.blank = blank ? 1u : 0u; d.pad = 0;
+        d.pad2[0] = d.pad2[1] = d.pad2[2] = d.pad2[3] = 0;
+        digest[e] = d;
+    }
+    const uint32_t Nm = O.Nmax, NP = C.n_props;
+    if (O.scalars && j < 7u) {
+        int32_t v = 0;
+        if (j == 6u) v = (int32_t)n_disc;
+        else if (!blank) {
+            if (j == 0u) v = (kind == MCBS_OUT_LEAKED_NODES || kind == MCBS_OUT_LEAKED_CREDENTIALS) ? (int32_t)new_nodes : 0;
+            else if (j == 1u) v = kind == MCBS_OUT_LATERAL_MOVE;
+            else if (j == 2u) v = kind == MCBS_OUT_CUSTOMER_DATA;
+            else if (j == 3u) v = kind == MCBS_OUT_PROBE_SUCCEEDED ? 2 : (kind == MCBS_OUT_PROBE_FAILED ? 1 : 0);
+            else if (j == 4u) v = kind == MCBS_OUT_PRIVILEGE_ESCALATION ? (int32_t)level : 0;
+            else v = (int32_t)n_creds;
+        }
+        O.scalars[(size_t)e * 7 + j] = v;
+    }
+    if (O.leaked) {
+        int32_t* out = O.leaked + (size_t)e * O.K * 4;
+        const bool have = !blank && kind == MCBS_OUT_LEAKED_CREDENTIALS;
+        for (uint32_t idx = j; idx < O.K * 4u; idx += 16u) {
+            const uint32_t r = idx >> 2, c = idx & 3u;
+            int32_t v = 0;
+            if (have && r < new_creds) {
+                const uint32_t ci = (n_creds - new_creds + r) & 15u;
+                v = c == 0 ? 1 : c == 1 ? (int32_t)(n_creds - new_creds + r) : c == 2 ? (int32_t)st.cred_ext[ci] : (int32_t)st.cred_port[ci];
+            }
+            out[idx] = v;
+        }
+    }
+    if (O.cache_matrix) {
+        int32_t* out = O.cache_matrix + (size_t)e * O.Cmax * 2;
+        for (uint32_t idx = j; idx < O.Cmax * 2u; idx += 16u) {
+            const uint32_t r = idx >> 1;
+            int32_t v = 0;
+            if (!blank && r < n_creds) v = (idx & 1u) ? (int32_t)st.cred_port[r & 15u] : (int32_t)st.cred_ext[r & 15u];
+            out[idx] = v;
+        }
+    }
+    if (O.props && NP) {
+        int32_t* out = O.props + (size_t)e * Nm * NP;
+        uint32_t i = j / NP, p = j - i * NP;
+        const uint32_t di = 16u / NP, dp = 16u - di * NP;
+        for (uint32_t idx = j; idx < Nm * NP; idx += 16u) {
+            int32_t v = blank ? 2 : 0;
+            if (!blank && i < n_disc) v = (int32_t)((st.props[i & 15u] >> p) & 1ull);
+            out[idx] = v;
+            p += dp; i += di;
+            if (p >= NP) { p -= NP; i += 1u; }
+        }
+    }
+    if (O.priv && j < Nm) O.priv[(size_t)e * Nm + j] = (!blank && j < n_disc) ? (int32_t)st.priv[j] : 0;
+}
+
 // One wavefront per env (every env, or the env's byte in env_mask decides: callers with sparse masks use obs_scan_kernel instead).
 __global__ __launch_bounds__(256) void obs_small_kernel(DevState S, Topo T, const StepCfg* __restrict__ Cp, ObsIO O, ObsDigest* digest) {
     const StepCfg& C = *Cp;   // device copy: by value it would push the arguments past 256 bytes (profiles/round1_notes.md)

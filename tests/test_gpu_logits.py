@@ -24,14 +24,14 @@ def test_mask_logits_equals_where_oracle_mask(trace):
     eng = engine.BatchEngine(topo, spec)
     orc = Oracle(topo, spec)
     A = eng.discrete_action_count()
-    small = ["scalars", "nodes_privilegelevel"]
-    obs = eng.alloc_obs(small)                          # NO mask field is requested from the observation
+    small = ["scalars", "leaked_credentials", "credential_cache_matrix", "discovered_nodes_properties", "nodes_privilegelevel"]
+    obs = eng.alloc_obs(small)                          # NO mask field is requested from the observation (<= 16 nodes: the 16-lanes-per-env kernel)
     g = torch.Generator(device=eng.device).manual_seed(1)
     fill = -1e8
     for t in range(50):
         a = eng.sample_actions(t % 5 != 4, seed=9, step=t)
         check = t % 7 == 6 or t == 49
-        oo = orc.alloc_obs(["mask_local", "mask_remote", "mask_connect"]) if check else None
+        oo = orc.alloc_obs(small + ["mask_local", "mask_remote", "mask_connect"]) if check else None
         if check:
             eng.step_observe(a, obs)
         else:
@@ -39,6 +39,8 @@ def test_mask_logits_equals_where_oracle_mask(trace):
         orc.step(a.cpu().numpy(), obs=oo)
         if not check:
             continue
+        for f in small:
+            np.testing.assert_array_equal(obs[f].cpu().numpy(), oo[f], err_msg=f"{trace} step {t} obs {f}")
         mask = np.concatenate([oo["mask_connect"].reshape(E, -1), oo["mask_local"].reshape(E, -1), oo["mask_remote"].reshape(E, -1)], axis=1) != 0
         assert mask.shape == (E, A)
         logits = torch.randn((E, A), generator=g, device=eng.device, dtype=torch.float32)
