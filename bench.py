@@ -404,6 +404,7 @@ def main() -> int:
         try:
             result["configs"] = extras_configs(W)
             result["observe"] = extras_observe(W)
+            result["wrapper"] = extras_wrapper()
         except Exception as exc:      # the headline stands on its own; an extras failure is reported, not hidden
             result["extras_error"] = f"{type(exc).__name__}: {exc}"
             parity_ok = False
@@ -529,6 +530,47 @@ def extras_observe(W):
             del obs3, logits
         eng.close()
         del ring
+        torch.cuda.empty_cache()
+    return out
+
+
+def extras_wrapper(K: int = 40):
+    """The tier a trainer consumes: one AttackerVecEnv.step (marlon's AttackerEnvWrapper + MaskedDiscreteAttackerWrapper for the whole batch:
+    decode, environment step, observation, bookkeeping, auto-reset) per call, 65 536 Chain-10 envs, valid Discrete actions drawn from the
+    action masks.  (a) as round 1 measured it: masks materialised, eager launches; (b) no mask written (the policy masks its logits with
+    mcbs_mask_logits) and the whole step replayed as one hipGraph.  Wall time per call on the host, synchronised at both ends."""
+    import torch
+    from marlon_amd.samples import chainpattern
+    from marlon_amd.wrappers import AttackerVecEnv
+    E = ENVS_PER_GPU
+    kw = dict(maximum_node_count=12, maximum_total_credentials=12, discrete=True)
+    ref = AttackerVecEnv(chainpattern.new_environment(10), E, **kw)              # supplies the masks the stand-in policy samples from
+    g = torch.Generator(device=ref.engine.device).manual_seed(0)
+    acts = []
+    for _ in range(K + 5):
+        m = ref.action_masks()
+        a = torch.where(m, torch.rand(m.shape, generator=g, device=m.device), torch.full((1,), -1.0, device=m.device)).argmax(dim=1)
+        acts.append(a)
+        ref.step(a)
+    ref.close()
+    del ref
+    torch.cuda.empty_cache()
+    out = []
+    for name, opts in (("masks materialised, eager launches", dict()), ("no mask materialised, whole step as one hipGraph", dict(materialize_masks=False, use_graph=True))):
+        env = AttackerVecEnv(chainpattern.new_environment(10), E, **kw, **opts)
+        for a in acts[:5]:
+            env.step(a)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rsum = 0.0
+        for a in acts[5:]:
+            _, r, _, _, _ = env.step(a)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / K
+        out.append({"workload": f"AttackerVecEnv.step, CyberBattleChain size=10, {E} envs, Discrete actions, {name}", "us_per_step": dt * 1e6,
+                    "env_steps_per_s": E / dt, "last_reward_sum": float(r.double().sum())})
+        env.close()
+        del env
         torch.cuda.empty_cache()
     return out
 
