@@ -384,3 +384,30 @@ def test_random_events_availability_bits_with_non_dyadic_weights():
         distinct.update(np.unique(av).tolist())
     assert len(distinct) > 20 and min(distinct) < 0.9          # services were stopped: many different non-trivial sums were compared
     eng.close()
+
+
+@pytest.mark.parametrize("trace", ["chain10_script", "toyctf_defender_s11", "random24_defender_s51"])
+def test_lds_staged_hot_image_equals_default(trace, monkeypatch):
+    """MCBS_LDS_TOPO=1 (read at batch creation) selects the step-kernel variant that stages the topology's hot image in LDS per
+    workgroup — round 1's default, kept for the launch-shape comparison in profiles/round2_notes.md.  Same actions, same Philox draws:
+    every output and the canonical state equal the default variant's (hot image through L1 / L2)."""
+    from marlon_amd._abi import RNG_PHILOX
+    _, sj = parity.load_trace(trace)
+    topo = parity.topology_for(trace)
+    E = 2048
+    spec = parity.spec_from_json(sj, n_envs=E, auto_reset=True, rng_kind=RNG_PHILOX, seed=123, max_episode_steps=80)
+    default = _engine().BatchEngine(topo, spec)
+    monkeypatch.setenv("MCBS_LDS_TOPO", "1")
+    staged = _engine().BatchEngine(topo, spec)
+    monkeypatch.delenv("MCBS_LDS_TOPO")
+    for t in range(160):
+        a = default.sample_actions(t % 4 != 0, seed=17, step=t)
+        r1, d1 = default.step(a)
+        r2, d2 = staged.step(a)
+        assert default.torch.equal(r1, r2) and default.torch.equal(d1, d2), f"step {t}"
+        for k in ("raw_reward", "truncated", "out_of_bound", "step_count", "network_availability"):
+            assert default.torch.equal(default.info[k], staged.info[k]), f"step {t} info {k}"
+        if t % 40 == 39:
+            _compare_states(default.get_state(), staged.get_state(), f"{trace} step {t}")
+    default.close()
+    staged.close()
