@@ -187,3 +187,76 @@ def test_graph_replayed_wrapper_step_equals_eager():
             ref.close()
     with pytest.raises(ValueError, match="draw tape"):
         AttackerVecEnv(parity.topology_for("toyctf"), 4, maximum_node_count=12, maximum_total_credentials=10, use_graph=True, rng_kind=1)
+
+
+def test_defender_vecenv_adapter_follows_the_reference_trace_to_its_first_episode_end():
+    """DefenderVecEnvAdapter (the SB3 VecEnv surface over DefenderVecEnv) on the joint attacker / defender trace captured from
+    marlon's DefenderEnvWrapper + LearningDefender: 4-tuple, float32 rewards, bool dones, per-env infos; up to the first episode end
+    every reward / done / observation equals the reference's, and that step carries terminal_observation + episode statistics."""
+    from marlon_amd import cyberbattle_env as ce
+    from marlon_amd.vecenv import DefenderVecEnvAdapter
+    from marlon_amd.wrappers import AttackerVecEnv, DefenderVecEnv
+    from tests.test_gpu_facades import DEF_KEYS
+    name = "wrap_defender_toyctf_s72"
+    z = np.load(os.path.join(parity.GOLDEN, name + ".npz"))
+    sj = json.loads(bytes(z["spec_json"]).decode())
+    att = AttackerVecEnv(parity.topology_for("toyctf"), 1, maximum_node_count=12, maximum_total_credentials=10,
+                         attacker_goal=ce.AttackerGoal(**sj["attacker_goal"]), defender_constraint=ce.DefenderConstraint(sj["maintain_sla"]),
+                         losing_reward=sj["losing_reward"], max_timesteps=sj["max_timesteps"], auto_reset=False, learned_defender=True)
+    env = DefenderVecEnvAdapter(DefenderVecEnv(att, max_timesteps=sj["max_timesteps"], invalid_action_reward=-1, loss_reward=-5000.0))
+    obs = env.reset()
+    for k in DEF_KEYS:
+        np.testing.assert_array_equal(obs[k][0], z["first_" + k])
+    ret, steps = 0.0, 0
+    for t in range(len(z["a_reward"])):
+        att.step(z["a_action"][t].reshape(1, 10))
+        if z["d_action"][t][0] <= -2:
+            break                                        # the attacker ended the episode first in the trace: nothing more to compare
+        step_result = env.step(z["d_action"][t].reshape(1, 12))
+        assert len(step_result) == 4
+        dobs, rewards, dones, infos = step_result
+        assert rewards.dtype == np.float32 and dones.dtype == np.bool_ and isinstance(infos[0], dict)
+        assert float(rewards[0]) == np.float32(z["d_reward"][t]), f"step {t} reward"
+        done = bool(z["d_terminated"][t] or z["d_truncated"][t])
+        assert bool(dones[0]) == done and infos[0]["valid_action"] == bool(z["d_valid"][t]), f"step {t}"
+        assert infos[0]["TimeLimit.truncated"] == bool(z["d_truncated"][t] and not z["d_terminated"][t])
+        ret += float(z["d_reward"][t])
+        steps += 1
+        if done:
+            for k in DEF_KEYS:
+                np.testing.assert_array_equal(infos[0]["terminal_observation"][k], z["d_" + k][t], err_msg=f"step {t} terminal {k}")
+            assert infos[0]["episode"]["l"] == steps and infos[0]["episode"]["r"] == ret
+            break
+        for k in DEF_KEYS:
+            np.testing.assert_array_equal(dobs[k][0], z["d_" + k][t], err_msg=f"step {t} {k}")
+    assert steps > 5
+    assert env.get_attr("max_timesteps") == [sj["max_timesteps"]] and env.env_is_wrapped(object) == [False]
+    att.close()
+
+
+def test_observe_masked_touches_only_the_flagged_envs():
+    """mcbs_observe_masked (the reset observation of the envs a VecEnv just reset; the mask is scanned 64 envs per wavefront): flagged
+    envs get exactly what a full mcbs_observe writes, the others keep their bytes — fused masks (Chain-10) and the separate mask
+    kernels of a larger action space (24 nodes)."""
+    import torch
+    from marlon_amd import engine
+    from marlon_amd._abi import RNG_PHILOX
+    for trace, E in (("chain10_mix_s3", 1000), ("random24_defender_s51", 200)):
+        _, sj = parity.load_trace(trace)
+        topo = parity.topology_for(trace)
+        spec = parity.spec_from_json(sj, n_envs=E, auto_reset=True, rng_kind=RNG_PHILOX, seed=3, max_episode_steps=50)
+        eng = engine.BatchEngine(topo, spec)
+        for t in range(30):
+            eng.step(eng.sample_actions(True, seed=2, step=t))
+        fields = list(parity.OBS_FIELDS) + ["mask_discrete"]
+        full = eng.observe(eng.alloc_obs(fields))
+        g = torch.Generator(device="cpu").manual_seed(1)
+        for density in (0.0, 0.02, 0.5, 1.0):
+            mask = (torch.rand(E, generator=g) < density).to(torch.uint8).to(eng.device)
+            part = {k: torch.full_like(v, 77) for k, v in full.items()}
+            eng.observe(part, env_mask=mask)
+            sel = mask.bool()
+            for k in fields:
+                assert torch.equal(part[k][sel], full[k][sel]), f"{trace} density {density} {k}: flagged envs"
+                assert bool((part[k][~sel] == 77).all()), f"{trace} density {density} {k}: other envs were touched"
+        eng.close()
