@@ -17,7 +17,8 @@ HBM ring (the replay is exact: attacker-only Chain has no randomness).  Weak sca
 barrier / MAX / gathers and an all_gather of episode returns after the timed region.
 
 The timed region replays the K steps from a hipGraph (launch-bound inner loop captured once), bracketed by
-barrier + synchronize on both sides.  The dominant kernel's average launch duration is measured in the same process
+barrier + synchronize on both sides (barrier, synchronize, K steps, synchronize, barrier; every rank times its own K steps between the two
+synchronizes and the job's time is the MAX over ranks).  The dominant kernel's average launch duration is measured in the same process
 with HIP events on the launch stream bracketing that timed region (/ K; a per-launch event-pair figure from an eager
 replay of the same K steps is printed beside it as an upper bound) and reported as a fraction of the HBM roofline.
 Beside the headline (never as `value`): `configs` — the step kernels of BASELINE.json's configs 3, 4 (one GPU's shard) and
@@ -296,8 +297,8 @@ def main() -> int:
             launch(Wm + t, t, st)
     ev1.record()
     torch.cuda.synchronize()
-    barrier()
-    elapsed_mine = time.perf_counter() - t0
+    elapsed_mine = time.perf_counter() - t0           # this rank's K steps, device work drained; the MAX over ranks below is the job's time
+    barrier()                                         # (the closing barrier brackets the region; its own latency is not part of the K steps)
     region_us = ev0.elapsed_time(ev1) * 1e3 / K          # device time per launch over the timed region, launch gaps included
     elapsed, per_rank = elapsed_mine, [elapsed_mine]
     if world > 1:
