@@ -221,7 +221,8 @@ class DefenderVecEnv:
     The learned defender always acts on the live environment."""
 
     def __init__(self, attacker: AttackerVecEnv, max_timesteps: int = 100, invalid_action_reward: float = 0.0,
-                 reset_on_constraint_broken: bool = True, loss_reward: float = -5000.0, sla_worsening_penalty_scale: float = 200.0):
+                 reset_on_constraint_broken: bool = True, loss_reward: float = -5000.0, sla_worsening_penalty_scale: float = 200.0,
+                 use_graph: bool = False):
         self.attacker = attacker
         self.engine = attacker.engine
         t = self.torch = attacker.torch
@@ -243,6 +244,11 @@ class DefenderVecEnv:
         self.valid_action_count = t.zeros(E, dtype=t.int64, device=dev)
         self.invalid_action_count = t.zeros(E, dtype=t.int64, device=dev)
         self._wb = None
+        # use_graph: the defender's turn (validity + executeAction + observation, reward shaping) captured once and replayed as one
+        # hipGraph; outputs are then the wrapper's own buffers (overwritten by the next step)
+        self.use_graph = bool(use_graph)
+        self._graph = None
+        self._act_in = t.zeros((E, 12), dtype=t.int64, device=dev)
         self.reset()
 
     @property
@@ -262,8 +268,7 @@ class DefenderVecEnv:
         self.prev_availability.copy_(t.where(keep, self.prev_availability, avail))    # in place: the fused shaping launch holds its address
         return self._obs
 
-    def step(self, actions):
-        """-> (observation dict, reward f64 [E], terminated u8 [E], truncated u8 [E], info)."""
+    def _step_device(self, actions):
         t = self.torch
         valid, avail, evicted = self.engine.defender_step(actions, self._obs)
         if self._wb is None:        # reward shaping (defend_wrapper.py:228-282) for the whole batch in one launch
@@ -279,6 +284,32 @@ class DefenderVecEnv:
             self._wc = DefenderWrapperCfg(self.invalid_action_penalty, self.loss_reward, self.sla_worsening_penalty_scale, self.maintain_sla,
                                           self.winning_reward, int(self.reset_on_constraint_broken), self.max_timesteps)
         self.engine.defender_wrapper_post(self._wb, self._wc)
+        return valid, avail
+
+    def step(self, actions):
+        """-> (observation dict, reward f64 [E], terminated u8 [E], truncated u8 [E], info)."""
+        t = self.torch
+        if self.use_graph:
+            a = actions if isinstance(actions, t.Tensor) else t.as_tensor(np.asarray(actions))
+            self._act_in.copy_(a.to(device=self.engine.device).reshape(self._act_in.shape), non_blocking=True)
+            if self._graph is None:
+                self._io = self._step_device(self._act_in)             # this turn runs eagerly ...
+                t.cuda.synchronize(self.engine.device)
+                g = t.cuda.CUDAGraph()
+                side = t.cuda.Stream(device=self.engine.device)
+                side.wait_stream(t.cuda.current_stream(self.engine.device))
+                with t.cuda.stream(side):
+                    with t.cuda.graph(g, stream=side):
+                        self._step_device(self._act_in)
+                t.cuda.current_stream(self.engine.device).wait_stream(side)
+                self._graph = g                                        # ... and is captured for the turns to come
+            else:
+                self._graph.replay()
+            valid, avail = self._io
+            info = {"valid_action": valid.view(t.bool), "network_availability": avail, "sla_breached": self._out["breached"].view(t.bool),
+                    "defender_won": self._out["won"].view(t.bool)}
+            return self._obs, self._out["reward"], self._out["terminated"], self._out["truncated"], info
+        valid, avail = self._step_device(actions)
         reward, terminated, truncated = self._out["reward"].clone(), self._out["terminated"].clone(), self._out["truncated"].clone()
         info = {"valid_action": valid.view(t.bool).clone(), "network_availability": avail.clone(), "sla_breached": self._out["breached"].view(t.bool).clone(),
                 "defender_won": self._out["won"].view(t.bool).clone()}

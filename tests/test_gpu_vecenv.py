@@ -260,3 +260,38 @@ def test_observe_masked_touches_only_the_flagged_envs():
                 assert torch.equal(part[k][sel], full[k][sel]), f"{trace} density {density} {k}: flagged envs"
                 assert bool((part[k][~sel] == 77).all()), f"{trace} density {density} {k}: other envs were touched"
         eng.close()
+
+
+def test_graph_replayed_defender_turn_equals_eager():
+    """DefenderVecEnv(use_graph=True) next to AttackerVecEnv(use_graph=True): the joint attacker / defender step as two hipGraph replays
+    returns what the eager wrappers return (rewards in fp64, flags, validity, availability bits, the four observation fields)."""
+    import torch
+    from marlon_amd import cyberbattle_env as ce
+    from marlon_amd.simulate import random_defender_policy
+    from marlon_amd.wrappers import AttackerVecEnv, DefenderVecEnv
+    E = 512
+    kw = dict(maximum_node_count=12, maximum_total_credentials=10, attacker_goal=ce.AttackerGoal(own_atleast=6),
+              defender_constraint=ce.DefenderConstraint(0.6), losing_reward=-5000.0, max_timesteps=60, auto_reset=False, learned_defender=True)
+    a1 = AttackerVecEnv(parity.topology_for("toyctf"), E, **kw)
+    a2 = AttackerVecEnv(parity.topology_for("toyctf"), E, use_graph=True, **kw)
+    d1 = DefenderVecEnv(a1, max_timesteps=60, invalid_action_reward=-1)
+    d2 = DefenderVecEnv(a2, max_timesteps=60, invalid_action_reward=-1, use_graph=True)
+    pol = random_defender_policy(4)
+    g = torch.Generator(device=a1.engine.device).manual_seed(2)
+    nvec = torch.as_tensor(a1.nvec, device=a1.engine.device, dtype=torch.float64)
+    for t in range(45):
+        act = (torch.rand((E, 10), generator=g, device=nvec.device, dtype=torch.float64) * nvec).long()
+        act[:, [1, 3, 4, 6, 7]] = act[:, [1, 3, 4, 6, 7]] % a1.observation["discovered_node_count"].long().clamp(min=1).unsqueeze(1)
+        _, r1, te1, tr1, _ = a1.step(act)
+        _, r2, te2, tr2, _ = a2.step(act)
+        assert torch.equal(r1, r2) and torch.equal(te1, te2) and torch.equal(tr1, tr2), f"attacker step {t}"
+        da = pol(d1)
+        o1, q1, x1, y1, i1 = d1.step(da)
+        o2, q2, x2, y2, i2 = d2.step(da)
+        assert torch.equal(q1.view(torch.int64), q2.view(torch.int64)) and torch.equal(x1, x2) and torch.equal(y1, y2), f"defender step {t}"
+        for k in ("valid_action", "network_availability", "sla_breached", "defender_won"):
+            assert torch.equal(i1[k], i2[k]), f"defender step {t} info {k}"
+        for k in o1:
+            assert torch.equal(o1[k], o2[k]), f"defender step {t} obs {k}"
+    assert bool((i1["network_availability"] < 1.0).any())            # re-imaging happened: the turns were not trivial
+    a1.close(); a2.close()
