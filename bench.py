@@ -563,7 +563,6 @@ def extras_wrapper(K: int = 40):
             env.step(a)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        rsum = 0.0
         for a in acts[5:]:
             _, r, _, _, _ = env.step(a)
         torch.cuda.synchronize()
