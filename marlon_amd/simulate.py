@@ -114,6 +114,57 @@ def run_episode(att: AttackerVecEnv, dfd: Optional[DefenderVecEnv] = None, attac
     return out
 
 
+def uniform_attacker_policy(seed: int = 0) -> Callable[[AttackerVecEnv], object]:
+    """`action_space.sample()` of AttackerEnvWrapper's MultiDiscrete space — what RandomMarlonAgent does when the wrapper exposes no
+    action masks (random_marlon_agent.py:72-96), i.e. in `marlon.simulate.simulate`'s default universe.  Mostly out-of-range actions."""
+    state = {"gen": None}
+
+    def policy(env: AttackerVecEnv):
+        t = env.torch
+        dev = env.engine.device
+        if state["gen"] is None:
+            state["gen"] = t.Generator(device=dev)
+            state["gen"].manual_seed(seed)
+        nvec = t.as_tensor(env.nvec, device=dev, dtype=t.float64)
+        return (t.rand((env.num_envs, 10), generator=state["gen"], device=dev, dtype=t.float64) * nvec).long()
+    return policy
+
+
+def simulate(timesteps: int, attacker_option: str = "Random", defender_option: str = "None", attacker_file=None, defender_file=None,
+             n_envs: int = 1, seed: int = 0, device: Optional[str] = None, maximum_node_count: int = 100, maximum_total_credentials: int = 1000,
+             maximum_discoverable_credentials_per_action: int = 5, attacker_action_masking: bool = False) -> Dict[str, object]:
+    """`marlon.simulate.simulate(timesteps, attacker_option, defender_option, attacker_file, defender_file)` (marlon/simulate.py:14-35) for a
+    batch of `n_envs` universes: `MultiAgentUniverse.build` (multiagent_universe.py:77-199) with its defaults — CyberBattleToyCtf-v0
+    (own_atleast 6, eviction goal), `max_timesteps=2000`, both invalid-action reward modifiers 0 as simulate passes them, and with a
+    defender `DefenderConstraint(maintain_sla=0.60)`, `losing_reward=-5000` — then one `run_episode(max_steps=timesteps)`.  Options:
+    'Random' (RandomMarlonAgent: uniform over the action masks if the wrapper has them, else uniform over the action space) and 'None'
+    (defender only).  'Load' needs Stable-Baselines3 / the Q-learning pickles of the reference and is not available here.
+    Returns run_episode's reward traces instead of the reference's plotly frames (rendering is out of scope)."""
+    from .cyberbattle_env import AttackerGoal, DefenderConstraint
+    from .samples import toy_ctf
+    if attacker_option == "None":
+        raise ValueError("Attacker cannot be none")
+    for opt in (attacker_option, defender_option):
+        if opt == "Load":
+            raise NotImplementedError("'Load' restores Stable-Baselines3 / Q-compatibility agents; neither library is part of this build")
+        if opt not in ("Random", "None"):
+            raise ValueError(f"unknown agent option {opt!r}")
+    with_defender = defender_option != "None"
+    kw = dict(maximum_node_count=maximum_node_count, maximum_total_credentials=maximum_total_credentials,
+              maximum_discoverable_credentials_per_action=maximum_discoverable_credentials_per_action,
+              attacker_goal=AttackerGoal(own_atleast=6), max_timesteps=2000, invalid_action_reward_modifier=0,
+              discrete=attacker_action_masking, auto_reset=False, device=device, seed=seed)
+    if with_defender:
+        kw.update(defender_constraint=DefenderConstraint(maintain_sla=0.60), losing_reward=-5000.0, learned_defender=True)
+    att = AttackerVecEnv(toy_ctf.new_environment(), n_envs, **kw)
+    dfd = DefenderVecEnv(att, max_timesteps=2000, invalid_action_reward=0, reset_on_constraint_broken=True, loss_reward=-5000.0) if with_defender else None
+    a_pol = random_policy(seed) if attacker_action_masking else uniform_attacker_policy(seed)
+    try:
+        return run_episode(att, dfd, a_pol, random_defender_policy(seed + 1) if with_defender else None, max_steps=timesteps)
+    finally:
+        att.close()
+
+
 def run_episodes(env: AttackerVecEnv, policy: Optional[Callable] = None, max_steps: int = 2000, record_actions: bool = False) -> Dict[str, object]:
     """Step every env of `env` (created with discrete=True for `random_policy`, auto_reset=True) for `max_steps` wrapper steps.
     Returns device tensors: `rewards` [max_steps, E], `dones` [max_steps, E], `episodes` [E] finished episode counts,

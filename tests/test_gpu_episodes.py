@@ -144,3 +144,19 @@ def test_run_episode_batch_with_random_agents():
 
 class AttackerVecEnvStub:
     auto_reset = True
+
+
+def test_simulate_entry_point():
+    """marlon.simulate.simulate's counterpart: option handling, the default universe (ToyCtf, invalid-action modifiers 0, SLA 0.60 and
+    losing reward -5000 with a defender), one episode per env bounded by `timesteps`."""
+    from marlon_amd.simulate import simulate
+    with pytest.raises(ValueError, match="Attacker cannot be none"):
+        simulate(10, "None", "None")
+    with pytest.raises(NotImplementedError, match="Stable-Baselines3"):
+        simulate(10, "Load", "None", attacker_file="ppo.zip")
+    out = simulate(60, "Random", "Random", n_envs=64, seed=3, maximum_node_count=12, maximum_total_credentials=10)
+    ar, dr, n = out["attacker_rewards"].cpu().numpy(), out["defender_rewards"].cpu().numpy(), out["lengths"].cpu().numpy()
+    assert ar.shape == dr.shape and ar.shape[1] == 64 and ar.shape[0] == out["steps"] <= 60 and (n >= 1).all() and n.max() == out["steps"]
+    assert (ar >= 0).all()                                  # modifier 0: an intercepted action costs nothing, penalties never surface (env.py:1169)
+    out2 = simulate(25, "Random", "None", n_envs=8, seed=1, maximum_node_count=12, maximum_total_credentials=10, attacker_action_masking=True)
+    assert out2["defender_rewards"] is None and out2["attacker_rewards"].shape == (25, 8) and float(out2["attacker_rewards"].sum()) > 0
