@@ -649,6 +649,7 @@ static int launch_obs(mcbs_batch* b, const mcbs_obs_buffers* o, hipStream_t st, 
         if (RL % 16 == 0 && RL / 16 <= 64 && reinterpret_cast<uintptr_t>(o->mask_connect) % 16 == 0) O.fuse_connect = 1;   // 16-byte chunks
         else if (dwords_ok && reinterpret_cast<uintptr_t>(o->mask_connect) % 4 == 0) O.fuse_connect = 2;                    // dwords, any RL
     }
+    O.nt_connect = (O.fuse_connect == 1 && M % 128 == 0 && reinterpret_cast<uintptr_t>(o->mask_connect) % 128 == 0) ? 1u : 0u;
     O.fuse_discrete = dwords_ok && o->mask_discrete && ML % 4 == 0 && MR % 4 == 0 && b->C.L > 0 && b->C.R > 0 &&
                       reinterpret_cast<uintptr_t>(o->mask_discrete) % 4 == 0;
     const uint32_t obs_shm = 4u * obs_stage_bytes(b->S.N, b->topo->H()->n_triples);

@@ -198,6 +198,7 @@ struct ObsIO {
     // masks, so that one launch writes the whole observation and the digest never makes a round trip through memory
     uint32_t fuse_remote;  // 1: mask_remote written by obs_small_kernel
     uint32_t fuse_connect; // 1: mask_connect written by obs_small_kernel (row length P*C a multiple of 16, 16-byte aligned)
+    uint32_t nt_connect;   // 1: the fused connect stream uses non-temporal stores (every env's mask is whole 128-byte lines)
     uint32_t fuse_discrete; // 1: mask_discrete (connect | local | remote per env, 4-byte granularity) written by obs_small_kernel
 };
 

@@ -18,6 +18,16 @@
 
 namespace mcbs {
 
+// The fused connect-mask stream (obs_env) uses NON-TEMPORAL 16-byte stores when every env's mask is a whole number of 128-byte lines
+// (Chain-10: 13 824 B): the gigabyte an observation writes is read back by nobody on this GPU before it falls out of every cache, and
+// not allocating it in L2 / Infinity Cache was worth 6-12 % (192 -> 171-186 us for 989 MB; profiles/round2_notes.md).  Where envs share
+// cache lines at their boundaries (mask_discrete: 14 172 B per env) non-temporal stores were SLOWER (213 -> 225 us, also when only the
+// interior lines used them), as they were for Chain-100's row kernel (35-70 GB per call, -4 %): those keep plain stores.
+__device__ __forceinline__ void stream_store16(uint4* p, const uint4 v) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store(u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4*>(p));
+}
+
 struct ObsDigest {          // 64 bytes per env
     uint64_t own_ext[4];    // bit i: the node at external index i has the agent installed
     uint32_t n_disc, n_creds, blank, pad;
@@ -273,7 +283,8 @@ __device__ __forceinline__ void obs_env(const DevState& S, const Topo& T, const 
         uint32_t q = lane / cpr, j = lane - q * cpr;
         for (uint32_t c = lane; c < total; c += 64u) {
             const uint4 p = st.pat[j];
-            out[c] = row_on(q) ? p : make_uint4(0, 0, 0, 0);
+            const uint4 v = row_on(q) ? p : make_uint4(0, 0, 0, 0);
+            if (O.nt_connect) stream_store16(out + c, v); else out[c] = v;      // (uniform)
             j += dj; q += dq;
             if (j >= cpr) { j -= cpr; q += 1u; }
         }
@@ -326,6 +337,7 @@ __device__ __forceinline__ void obs_env(const DevState& S, const Topo& T, const 
             }
             const uint32_t nchunks = (M - h) >> 4, dq = 64u / cpr, dj = 64u - dq * cpr;
             uint4* out16 = reinterpret_cast<uint4*>(base + h);
+
             uint32_t q = (h + lane * 16u) / RL, j = ((h + lane * 16u) - q * RL - h) >> 4;
             // bytes [0, 16 - h) of a straddling chunk belong to row q, the rest to row q + 1
             const uint32_t nb = 16u - h;
