@@ -646,8 +646,12 @@ static int launch_obs(mcbs_batch* b, const mcbs_obs_buffers* o, hipStream_t st, 
     const bool dwords_ok = small && RL >= 4 && RL + 4 <= 1040 && M % 4 == 0;     // the row pattern fits its kilobyte of LDS
     O.fuse_connect = 0;
     if (small && o->mask_connect) {
+        size_t g16 = 16;
+        while (RL % g16) g16 >>= 1;                                                                                          // gcd(RL, 16)
         if (RL % 16 == 0 && RL / 16 <= 64 && reinterpret_cast<uintptr_t>(o->mask_connect) % 16 == 0) O.fuse_connect = 1;   // 16-byte chunks
-        else if (dwords_ok && reinterpret_cast<uintptr_t>(o->mask_connect) % 4 == 0) O.fuse_connect = 2;                    // dwords, any RL
+        else if (RL >= 16 && RL / g16 <= 64 && M % 16 == 0 && reinterpret_cast<uintptr_t>(o->mask_connect) % 16 == 0 && !b->slow_masks) {
+            O.fuse_connect = 3; O.conn_pc = (uint32_t)(RL / g16);                                                            // 16-byte chunks, any RL >= 16
+        } else if (dwords_ok && reinterpret_cast<uintptr_t>(o->mask_connect) % 4 == 0) O.fuse_connect = 2;                  // dwords, any RL
     }
     O.nt_connect = (O.fuse_connect == 1 && M % 128 == 0 && reinterpret_cast<uintptr_t>(o->mask_connect) % 128 == 0) ? 1u : 0u;
     O.fuse_discrete = dwords_ok && o->mask_discrete && ML % 4 == 0 && MR % 4 == 0 && b->C.L > 0 && b->C.R > 0 &&

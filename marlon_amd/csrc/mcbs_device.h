@@ -197,7 +197,9 @@ struct ObsIO {
     // small action spaces (<= 256 (source, target) pairs): the per-env wavefront of obs_small_kernel also streams the two big
     // masks, so that one launch writes the whole observation and the digest never makes a round trip through memory
     uint32_t fuse_remote;  // 1: mask_remote written by obs_small_kernel
-    uint32_t fuse_connect; // 1: mask_connect written by obs_small_kernel (row length P*C a multiple of 16, 16-byte aligned)
+    uint32_t fuse_connect; // mask_connect written by obs_small_kernel: 1 = 16-byte chunks, row length P*C a multiple of 16; 2 = dwords, any row
+                           // length; 3 = 16-byte chunks for row lengths that are NOT a multiple of 16 (ToyCtf: 70), pattern of one lcm period
+    uint32_t conn_pc;      // fuse_connect == 3: chunks per pattern period, lcm(P*C, 16) / 16
     uint32_t nt_connect;   // 1: the fused connect stream uses non-temporal stores (every env's mask is whole 128-byte lines)
     uint32_t fuse_discrete; // 1: mask_discrete (connect | local | remote per env, 4-byte granularity) written by obs_small_kernel
 };

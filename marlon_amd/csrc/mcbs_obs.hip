@@ -260,6 +260,46 @@ __device__ __forceinline__ void obs_env(const DevState& S, const Topo& T, const 
             if (r >= RL) { r -= RL; q += 1u; }
         }
     };
+    if (O.fuse_connect == 3u) {
+        // Row lengths that are not a multiple of 16 (ToyCtf: 7 ports x 10 credentials = 70 bytes), still 16 bytes per lane and store: the
+        // byte stream of an all-on env repeats every lcm(RL, 16) bytes = conn_pc chunks (35 for RL = 70), lane j builds chunk j of that period
+        // once per env, and chunk c of the env is pattern[c mod conn_pc] with the bytes of the (at most two) rows it touches switched on or
+        // off.  (row, offset in row, pattern index) advance incrementally by 64 chunks per iteration.
+        const uint32_t Cc = O.Cmax, RL = C.P * Cc, PC = O.conn_pc;
+        __builtin_amdgcn_wave_barrier();               // (an earlier pattern may still be in use by other lanes)
+        if (lane < PC) {
+            uint32_t r = (lane * 16u) % RL, c = r % Cc, w[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (uint32_t i = 0; i < 16u; ++i) {
+                w[i >> 2] |= (uint32_t)(c < n_creds) << (8u * (i & 3u));
+                r += 1u; c += 1u;
+                if (c == Cc) c = 0u;
+                if (r == RL) { r = 0u; c = 0u; }
+            }
+            st.pat[lane] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        uint4* out = reinterpret_cast<uint4*>(O.mask_connect + (size_t)e * rows * RL);
+        const uint32_t total = (rows * RL) >> 4, dq = 1024u / RL, dr = 1024u - dq * RL, dj = 64u % PC;
+        uint32_t q = (lane * 16u) / RL, r0 = lane * 16u - q * RL, pj = lane % PC;
+        for (uint32_t c = lane; c < total; c += 64u) {
+            const uint4 p = st.pat[pj];
+            const uint32_t b = RL - r0;                                  // bytes of this chunk inside row q (>= 16: all)
+            const uint32_t a0 = st.onb[q] ? 0xFFFFFFFFu : 0u, a1 = st.onb[q + 1u] ? 0xFFFFFFFFu : 0u;
+            uint32_t sel[4];
+#pragma unroll
+            for (uint32_t d4 = 0; d4 < 4u; ++d4) {
+                const uint32_t lo = 4u * d4;                             // dword d4 holds bytes lo .. lo + 3 of the chunk
+                const uint32_t m = b >= lo + 4u ? 0xFFFFFFFFu : (b <= lo ? 0u : ((1u << (8u * (b - lo))) - 1u));
+                sel[d4] = (a0 & m) | (a1 & ~m);
+            }
+            out[c] = make_uint4(p.x & sel[0], p.y & sel[1], p.z & sel[2], p.w & sel[3]);
+            r0 += dr; q += dq; pj += dj;
+            if (r0 >= RL) { r0 -= RL; q += 1u; }
+            if (pj >= PC) pj -= PC;
+        }
+    }
     if (O.fuse_connect == 2u) stream_connect_dwords(reinterpret_cast<uint32_t*>(O.mask_connect + (size_t)e * rows * C.P * O.Cmax));
     if (O.fuse_connect == 1u) {
         // connect[s][t][p][c] = on(s, t) && c < n_creds.  An "on" row is RL = P*C bytes of the pattern "n_creds ones, C - n_creds
