@@ -8,8 +8,9 @@
 //     gathered-credential and cached-triple sets;
 //   * one "body" record per env (array-of-structures, stride body_stride): the discovery order (u8 node
 //     ids) and the credential cache (u16 triple ids) first — their first 16 entries each are fetched with
-//     the header, before the action is decoded — then 32-byte node rows (discovered-property mask,
-//     attacked-ever / attacked-since-reimage slot masks, privilege, tags, re-imaging countdown).  Rows are
+//     the header, before the action is decoded — then 16-byte node rows {discovered-property mask + privilege_k
+//     tags, attacked-ever and attacked-since-reimage slot masks} (packed batches: 4 bytes per row; privilege levels, the
+//     running flags and the re-imaging countdown live in the set columns and the re-imaging ring).  Rows are
 //     gathered by node id, which differs per env, so they sit next to each other per env rather than
 //     along the env axis.
 //   * the topology blob (include/mcbs.h "MCBT") is shared by every env and read-only.

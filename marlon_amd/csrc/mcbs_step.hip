@@ -5,24 +5,34 @@
 // integer / boolean work, O(1) per step once the per-env sets are bit masks), so spending a whole
 // wavefront on one env would idle 63 lanes; wave-level cooperation is used where it exists — the
 // coalesced re-initialisation of an env that just ended (ballot over the lanes that need a reset, then
-// all 64 lanes copy the reset image), the cooperative staging of the topology tables in LDS, and the
-// observation kernels (mcbs_obs.hip).
+// all 64 lanes copy the reset image) and the observation kernels (mcbs_obs.hip).
 //
 // At BASELINE.json's batch (65 536 envs = 1 024 wavefronts on 1 024 SIMDs) every wavefront is resident at
-// once, so the launch takes as long as ONE wavefront's dependent chain of memory accesses.  The kernel is
-// therefore organised by dependency level, not by reference function:
+// once, so the launch takes as long as ONE wavefront's dependent chain of memory accesses (two thirds of a
+// wavefront's cycles are parked at s_waitcnt: profiles/round2_notes.md).  The kernel is therefore organised by
+// dependency level, not by reference function:
+//   prologue: ONE batch of kernel-argument loads, then
 //   level 1 (addresses depend on the env index only, issued back to back, all coalesced along the env axis):
 //           header uint4, action row, first 16 discovery-order entries, first 16 credential-cache entries,
 //           EVERY set of the env as u64 bit-mask words (discovered, agent installed, ever owned, running,
-//           privilege bit-planes, gathered credentials, cached credential triples), {cum_reward, availability};
-//           meanwhile the workgroup copies the topology tables into LDS;
+//           privilege bit-planes, gathered credentials, cached credential triples; packed batches: one uint4 and
+//           every 4-byte node row), {cum_reward, availability}; the config words (action-space bounds, goal
+//           constants) are fetched through the config pointer AFTER these are in flight;
 //   level 2 (address depends on the action / header): the target node's 16-byte row, the re-imaging ring slot
-//           of this defender tick (and list entries beyond the first 16 for large topologies);
-//   then pure register + LDS work (vulnerability descriptor, payload, firewall / authorisation tables, Philox), and
-//   one round of stores (row, sets, list appends, header, outputs).  "Rare" events are not rare per wavefront
-//   (64 envs), so nothing on those paths may cost another trip to memory: a first version that tested the
-//   ever-owned / discovered / credential sets lazily in memory spent 9 of its 10 dependency levels there
-//   (profiles/round1_notes.md).
+//           of this defender tick (list entries beyond the first 16 for large topologies come first), and the
+//           EIGHT loads from the topology's hot image — node record, source firewall word, authorisation word
+//           (indexed by triple id), the 64-byte vulnerability descriptor with the first four leak entries inline —
+//           through L1 / L2, fenced so that they go out together (leak entries 4..7: one more, wave-uniformly
+//           skipped, batch);
+//   ONE explicit wait for everything, in straight-line code; then pure register work and
+//   one round of stores (row, sets, list appends, header, outputs) with NO load behind any store: on gfx9 vector
+//   loads and stores retire in order on one counter, so a load behind a store waits for the write
+//   acknowledgement, and a wait placed under divergent control flow can only be vmcnt(0).  "Rare" events are not
+//   rare per wavefront (64 envs), so nothing on those paths may cost another trip to memory: a first version that
+//   tested the ever-owned / discovered / credential sets lazily in memory spent 9 of its 10 dependency levels there
+//   (profiles/round1_notes.md).  Round 1 staged the hot image in LDS per workgroup; reading it through L1 / L2
+//   with one-wavefront workgroups measured faster at every BASELINE shape (TOPO_LDS = true survives behind
+//   MCBS_LDS_TOPO=1 for the comparison).
 //
 // Control flow.  The lanes of a wavefront hold different action kinds, outcomes and validity, so every `if` of the
 // reference that the compiler keeps as a branch is paid by the whole wave (compare, exec-mask save, branch, restore:
