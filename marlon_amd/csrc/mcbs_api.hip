@@ -531,8 +531,8 @@ static int timing_end(mcbs_batch* b, hipStream_t st, size_t slot) {
     return MCBS_OK;
 }
 
-// Kernel variant: words per set kept in registers (1, 2 or 4), whether the topology tables fit the LDS budget, and
-// whether an in-env defender is configured (its code and loads are compiled out otherwise).
+// Kernel variant: words per set kept in registers (1, 2 or 4; 0 = packed batch), where the topology's hot image is read from, and
+// which defender is configured (its code and loads are compiled out otherwise).
 template <int PHASE, int WT, int DEF, bool MANY = false>
 static void launch_step_v(mcbs_batch* b, const StepIO& io, hipStream_t st, const RollArgs& roll = RollArgs{}) {
     const uint32_t E = b->S.E, lds = b->C.hot_bytes;

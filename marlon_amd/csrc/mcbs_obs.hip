@@ -11,8 +11,12 @@
 //                      node -> external-index map in LDS, ballot the "source is owned" bits, and stream out the
 //                      small fields with lane-strided (coalesced) stores.  It also leaves a 64-byte digest per
 //                      env (owned-source bits, counts, blank flag) for the mask kernel.
-//   mask_kernel      : one thread per W output bytes of a mask region (W = 16 when the per-env size allows
-//                      16-byte stores, else 4 or 1); reads only the digest.
+//                      For action spaces of up to 256 (source, target) pairs the same wavefront streams the big masks too.
+//   obs_scan_kernel  : the same per-env routine for mcbs_observe_masked (the envs a VecEnv just reset): a wavefront scans 64
+//                      envs' mask bytes and writes the flagged ones, so a sparse mask costs next to nothing.
+//   obs_tiny_kernel  : mask-less observations of topologies with <= 16 nodes: SIXTEEN LANES per env, four envs per wavefront.
+//   mask_connect_rows_kernel / mask_fast_kernel / mask_kernel : the big masks of larger action spaces, from the digest alone
+//                      (rows of 16-byte chunks with the pattern in LDS; generic 16-byte chunk builder; byte walker).
 #pragma once
 #include "mcbs_device.h"
 
