@@ -111,9 +111,9 @@ class MarlonVecEnv:
         invalid = _to_numpy(info["invalid_action"]).astype(bool)
         avail, steps = _to_numpy(info["network_availability"]), _to_numpy(info["step_count"])
         # DummyVecEnv.step_wait: info["TimeLimit.truncated"] = truncated and not terminated
-        infos = _InfoList({"invalid_action": bool(invalid[i]), "cyber_step_executed": bool(not invalid[i]),
-                           "network_availability": float(avail[i]), "step_count": int(steps[i]),
-                           "TimeLimit.truncated": bool(trunc[i] and not term[i])} for i in range(self.num_envs))
+        # (plain Python lists first: one dict per env is what SB3 wants, but per-element NumPy conversions would dominate at 65 536 envs)
+        infos = _InfoList({"invalid_action": iv, "cyber_step_executed": not iv, "network_availability": av, "step_count": sc, "TimeLimit.truncated": tl}
+                          for iv, av, sc, tl in zip(invalid.tolist(), avail.tolist(), steps.tolist(), (trunc & ~term).tolist()))
         ended = np.flatnonzero(dones)
         if ended.size:
             sel = v.torch.as_tensor(ended, device=v.engine.device)
@@ -234,8 +234,8 @@ class DefenderVecEnvAdapter:
         term, trunc = _to_numpy(terminated).astype(bool), _to_numpy(truncated).astype(bool)
         dones = term | trunc
         valid, avail = _to_numpy(info["valid_action"]), _to_numpy(info["network_availability"])
-        infos = _InfoList({"valid_action": bool(valid[i]), "network_availability": float(avail[i]),
-                           "TimeLimit.truncated": bool(trunc[i] and not term[i])} for i in range(self.num_envs))
+        infos = _InfoList({"valid_action": bool(va), "network_availability": av, "TimeLimit.truncated": tl}
+                          for va, av, tl in zip(valid.tolist(), avail.tolist(), (trunc & ~term).tolist()))
         ended = np.flatnonzero(dones)
         if ended.size:
             ret, length = _to_numpy(self._ret), _to_numpy(self._len)
