@@ -1,0 +1,46 @@
+"""The driver's benchmark contract, exercised on the GPU box: `python bench.py --gpus 1 --steps K --warmup W` prints ONE JSON line with the
+fields the contract names, the parity flags hold (the metric says "bit-exact vs CPU ref": a run whose checks fail prints value null and exits
+non-zero), the roofline block is consistent with the timed region, and the counter files under profiles/ belong to the kernels being timed."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def test_bench_line_contract_small_run():
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "40", "--warmup", "10", "--cpu-seconds", "1",
+                        "--envs-per-gpu", "65536"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    b = json.loads(lines[0])
+    assert b["metric"] == "env-steps/sec at 65536 envs, CyberBattleChain-10; bit-exact vs CPU ref" and b["unit"] == "env-steps/s"
+    assert b["n_gpus"] == 1 and b["steps"] == 40 and b["warmup"] == 10 and b["higher_is_better"] is True and b["scaling"] == "weak"
+    assert b["vs_baseline"] is None and b["dtype"] == "int32" and b["data"] == "synthetic" and "workload" in b["config"]
+    assert b["parity_ok"] is True and b["value"] is not None
+    assert abs(b["value"] - 65536 * 40 / (b["ms_per_step"] * 40 * 1e-3)) / b["value"] < 1e-6           # value = envs x steps / timed region
+    assert b["value"] > 1e9                                                                              # (target: 1e7)
+    r = b["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert abs(r["achieved"] - 348 * 65536 / (r["kernel_us"] * 1e-6) / 1e9) / r["achieved"] < 1e-6       # algorithmic bytes / measured kernel time
+    assert r["kernel_us"] <= b["ms_per_step"] * 1e3 * 1.05                                               # device time per launch fits the wall time per step
+    assert r["replay_rewards_and_dones_equal_timed_region"] is True and b["step_many"]["rewards_and_dones_equal_timed_region"] is True
+    src = r["traffic_source"]
+    assert src["status"] in ("current", "missing") or src["status"].startswith("stale"), src
+    if src["status"] == "current":                                                                       # counters taken on THESE kernel sources
+        assert r["traffic"] is not None and 100 * 65536 < r["traffic"] < 400 * 65536
+    else:
+        assert r["traffic"] is None
+    c = b["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["rewards_and_dones_equal_gpu"] is True and c["all_cores"]["rewards_and_dones_equal_gpu"] is True
+    assert c["reference_python"]["kind"] == "reference" and c["reference_python"]["value"] > 500
+    assert [x["name"] for x in b["configs"]] == ["config3", "config4", "config5"] and all(x["us_per_step"] > 0 for x in b["configs"])
+    assert {x["name"] for x in b["observe"]} >= {"headline", "headline_discrete", "headline_mask_logits", "config3"}
+    w = b["wrapper"]
+    assert len(w) == 2 and w[0]["last_reward_sum"] == w[1]["last_reward_sum"] and w[1]["us_per_step"] < w[0]["us_per_step"]
+    assert "extras_error" not in b
