@@ -141,6 +141,7 @@ class CyberBattleEnv:
         self.__throws = throws_on_invalid_actions
         self.__WINNING_REWARD, self.__LOSING_REWARD = winning_reward, losing_reward
         self.__defender_agent = defender_agent
+        self.__defender_constraint, self.__defender_goal, self.__attacker_goal = defender_constraint, defender_goal, attacker_goal
         self._engine = BatchEngine(self.topo, self.spec, device=device)      # raises ValueError like validate_environment
         ids = initial_environment.identifiers
         self.__bounds = EnvironmentBounds(maximum_total_credentials, maximum_node_count, maximum_discoverable_credentials_per_action,
@@ -171,6 +172,29 @@ class CyberBattleEnv:
     @property
     def unwrapped(self):
         return self
+
+    @property
+    def environment(self) -> model.Environment:
+        """`CyberBattleEnv.environment` (cyberbattle_env.py:371), as a SNAPSHOT: a copy of the initial model whose nodes carry the dynamic
+        fields the device state holds — agent_installed, privilege_level, status (Running / Imaging) and the privilege_k tags appended to
+        node.properties (actions.py:378).  Read-only: the state lives on the GPU, edits of the copy do not reach it (marlon's defender
+        acts through DefenderVecEnv / mcbs_defender_step instead of mutating this object)."""
+        import copy
+        env = copy.deepcopy(self.__initial_environment)
+        _, nodes, _, _ = self._engine.get_state()
+        for i, (node_id, info) in enumerate(env.nodes()):
+            info.agent_installed = bool(nodes["installed"][0][i])
+            info.privilege_level = model.PrivilegeLevel(int(nodes["privilege"][0][i]))
+            info.status = model.MachineStatus.Running if nodes["running"][0][i] else model.MachineStatus.Imaging
+            for k in range(4):
+                tag = f"privilege_{k}"
+                if (int(nodes["tags"][0][i]) >> k) & 1 and tag not in info.properties:
+                    info.properties.append(tag)
+        return env
+
+    def __defender_goal_reached(self) -> bool:
+        """`__defender_goal_reached` (cyberbattle_env.py:1112-1116): eviction asked for and no node left with privilege >= LocalUser."""
+        return bool(self.__defender_goal.eviction) and not bool((self.__privilege_by_node >= 1).any())
 
     # ---- helpers ----
     def __refresh_lists(self) -> None:

@@ -303,3 +303,28 @@ def test_defender_step_batch_against_oracle():
 def _engine_mod():
     from marlon_amd import engine
     return engine
+
+
+def test_gym_facade_exposes_what_marlons_callers_read():
+    """The attributes marlon's wrappers and simulation helpers read through name mangling (attack_wrapper.py:71-72,118;
+    defend_wrapper.py:52,260-261; multiagent/simulation.py:22,36): discovered nodes, winning / losing reward, defender constraint,
+    defender goal test, episode rewards, and `environment` as a snapshot of the live model."""
+    from marlon_amd import cyberbattle_env as ce
+    from marlon_amd import model
+    env = ce.CyberBattleChain(size=4, maximum_node_count=6, maximum_total_credentials=6, throws_on_invalid_actions=False, losing_reward=-7.0,
+                              defender_constraint=ce.DefenderConstraint(maintain_sla=0.6))
+    env.reset(seed=0)
+    assert env._CyberBattleEnv__WINNING_REWARD == 5000.0 and env._CyberBattleEnv__LOSING_REWARD == -7.0
+    assert env._CyberBattleEnv__defender_constraint.maintain_sla == 0.6
+    assert env._CyberBattleEnv__discovered_nodes == ["start"] and env._CyberBattleEnv__episode_rewards == []
+    assert env._CyberBattleEnv__defender_goal_reached() is False             # the start node is owned
+    snap = env.environment
+    assert isinstance(snap, model.Environment) and [n for n, _ in snap.nodes()][0] == "start"
+    start = snap.get_node("start")
+    assert start.agent_installed and start.privilege_level >= model.PrivilegeLevel.LocalUser and start.status == model.MachineStatus.Running
+    assert not snap.get_node("1_LinuxNode").agent_installed
+    obs, r, done, _, _ = env.step({"local_vulnerability": np.array([0, 1])})   # ScanExplorerRecentFiles: discovers 1_LinuxNode
+    assert env._CyberBattleEnv__discovered_nodes == ["start", "1_LinuxNode"] and env._CyberBattleEnv__episode_rewards == [r]
+    snap.get_node("start").agent_installed = False                           # a snapshot: editing it does not touch the device state
+    assert env.environment.get_node("start").agent_installed
+    env.close()
