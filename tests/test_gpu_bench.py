@@ -44,3 +44,20 @@ def test_bench_line_contract_small_run():
     w = b["wrapper"]
     assert len(w) == 2 and w[0]["last_reward_sum"] == w[1]["last_reward_sum"] and w[1]["us_per_step"] < w[0]["us_per_step"]
     assert "extras_error" not in b
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """The N > 1 path end to end on the one-GPU box: `python bench.py --gpus 2 --single-device` starts its two ranks itself (both on
+    cuda:0), the ranks agree on a collective backend (RCCL refuses two ranks on one device, so gloo), each owns its own 65 536-env shard
+    (global env ids rank * E ...), and rank 0 reports the whole-job throughput from the MAX of the per-rank times."""
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--single-device", "--steps", "60", "--warmup", "10",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    b = json.loads(lines[0])
+    assert b["n_gpus"] == 2 and b["ranks_in_group"] == 2 and b["self_launched"] is True and b["collective_backend"] in ("gloo", "nccl")
+    assert len(b["per_rank_ms_per_step"]) == 2 and b["parity_ok"] is True and b["scaling"] == "weak"
+    assert abs(b["ms_per_step"] - max(b["per_rank_ms_per_step"])) < 1e-9                                # MAX over ranks
+    assert abs(b["value"] - 2 * 65536 * 60 / (b["ms_per_step"] * 60 * 1e-3)) / b["value"] < 1e-6       # aggregate over both ranks
+    assert "configs" not in b                                                                            # the extra legs run at N = 1 only
