@@ -858,13 +858,13 @@ extern "C" int mcbs_mask_logits(mcbs_batch* b, void* logits, int32_t dtype, size
     G.N = b->cfg.maximum_node_count; G.C = b->cfg.maximum_total_credentials; G.L = b->C.L; G.R = b->C.R; G.RL = b->C.P * G.C;
     G.M = G.N * G.N * G.RL; G.ML = G.N * G.L; G.A = (uint32_t)A64;
     G.dRL = fast_div_host(G.RL); G.dC = fast_div_host(G.C); G.dN = fast_div_host(G.N); G.dL = fast_div_host(G.L); G.dR = fast_div_host(G.R);
-    constexpr int U = 4;
     hipStream_t st = (hipStream_t)stream;
     const uintptr_t p0 = reinterpret_cast<uintptr_t>(logits);
-    auto grid_for = [&](uint32_t gw) { return dim3((G.A + 256u * gw * U - 1u) / (256u * gw * U), b->S.E); };
+    // one wavefront per env, four per workgroup; very large action spaces split their chunks of 64 spans over grid.x
+    auto grid_for = [&](uint32_t gw) { const uint32_t chunks = (((G.A + gw - 1u) / gw + 15u + 63u) / 64u + 63u) / 64u;   /* spans are shifted by up to 15 groups */ return dim3(chunks < 64u ? chunks : 64u, (b->S.E + 3u) / 4u); };
     const dim3 block(256);
 #define MCBS_LOGITS_LAUNCH(LT_, GW_, VEC_, PTR_, FILL_) \
-    hipLaunchKernelGGL((mask_logits_kernel<LT_, GW_, U, VEC_>), grid_for(GW_), block, 0, st, b->S, b->T, b->C_dev, b->digest, PTR_, row_stride, FILL_, G)
+    hipLaunchKernelGGL((mask_logits_kernel<LT_, GW_, VEC_>), grid_for(GW_), block, 0, st, b->S, b->T, b->C_dev, b->digest, PTR_, row_stride, FILL_, G)
     if (dtype == MCBS_LOGITS_F32) {
         float* lp = static_cast<float*>(logits);
         if ((row_stride * 4) % 16 == 0 && p0 % 16 == 0) MCBS_LOGITS_LAUNCH(float, 4u, true, lp, fill);

@@ -5,6 +5,7 @@
     python3 tools/profile_run.py obs:<workload> [K]       K mcbs_observe launches of the whole observation (reference dtypes)
     python3 tools/profile_run.py discrete:<workload> [K]  K mcbs_observe launches of the small fields + mask_discrete (MaskablePPO path)
     python3 tools/profile_run.py logits:<workload> [K]    K mcbs_mask_logits launches (on-device mask -> logits, no mask materialised)
+    python3 tools/profile_run.py wrapper:<workload> [K]   K AttackerVecEnv.step calls (Discrete actions, no mask materialised, hipGraph replay)
 workload: headline | config2 | config3 | config4 | config5  (tools/workloads.py)
 
 The recording rollout uses a throw-away engine; its launches are in the trace too (same kernels, same shapes), which only adds
@@ -19,6 +20,32 @@ from tools import workloads as W  # noqa: E402
 
 what, name = sys.argv[1].split(":")
 K = int(sys.argv[2]) if len(sys.argv) > 2 else (200 if what == "step" else 10)
+if what == "wrapper":
+    import time
+    from marlon_amd.wrappers import AttackerVecEnv
+    topo_env, E, kw = W.wrapper_workload(name)
+    venv = AttackerVecEnv(topo_env, E, discrete=True, materialize_masks=False, use_graph=os.environ.get("WRAPPER_GRAPH", "1") == "1", **kw)
+    ref = AttackerVecEnv(topo_env, E, discrete=True, **kw)                     # supplies the masks a random valid policy samples from
+    venv.reset(), ref.reset()
+    g = torch.Generator(device=venv.engine.device)
+    g.manual_seed(0)
+    acts = []
+    for _ in range(K + 5):
+        m = ref.action_masks()
+        a = torch.where(m, torch.rand(m.shape, generator=g, device=m.device), torch.full((1,), -1.0, device=m.device)).argmax(dim=1)
+        ref.step(a)
+        acts.append(a)
+    ref.close()
+    for a in acts[:5]:
+        venv.step(a)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for a in acts[5:]:
+        venv.step(a)
+    torch.cuda.synchronize()
+    print(json.dumps(dict(what=what, workload=name, envs=E, launches=K, us_per_step=(time.perf_counter() - t0) / K * 1e6)))
+    venv.close()
+    raise SystemExit(0)
 ring = W.record_ring(name, K if what == "step" else 40)
 eng, topo, spec, desc = W.make_engine(name)
 out = dict(what=what, workload=name, envs=eng.E, launches=K, desc=desc)
@@ -37,12 +64,13 @@ elif what in ("obs", "discrete"):
 elif what == "logits":
     for t in range(40):
         eng.step(ring[t], with_info=False)
+    eng.observe(eng.alloc_obs(W.OBS_FIELDS[:5]))          # the digest the mask is rebuilt from is left by the last observation
     n_act = eng.discrete_action_count()
     logits = torch.zeros((eng.E, n_act), dtype=torch.float32, device=eng.device)
     for _ in range(K):
         eng.mask_logits(logits, fill=-1e8)
     torch.cuda.synchronize()
-    out.update(bytes_per_env=n_act * 4 * 2)
+    out.update(bytes_per_env=4.0 * float((logits != 0).sum()) / eng.E, logits_bytes_per_env=n_act * 4)      # write-only: 4 B per masked-out action
 else:
     raise SystemExit(f"unknown workload kind {what}")
 print(json.dumps(out))

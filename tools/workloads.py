@@ -46,6 +46,16 @@ def workload(name: str):
     raise KeyError(name)
 
 
+def wrapper_workload(name: str):
+    """(reference-style environment, envs, AttackerVecEnv keyword arguments) of the wrapper tier's two workloads."""
+    from marlon_amd.samples import chainpattern, toy_ctf
+    if name == "headline":
+        return chainpattern.new_environment(10), 65536, dict(maximum_node_count=12, maximum_total_credentials=12)
+    if name == "config3":
+        return toy_ctf.new_environment(), 16384, dict(maximum_node_count=12, maximum_total_credentials=10)
+    raise KeyError(name)
+
+
 def make_engine(name: str, n_envs: int = 0, env_id_base: int = 0, device: str = "cuda:0", max_episode_steps: int = 2000, seed: int = 7):
     from marlon_amd import engine
     from marlon_amd._abi import EnvSpec
