@@ -406,6 +406,7 @@ typedef struct mcbs_wrapper_buffers {
     double*  episode_return_out;   /* out: copies for the info dict, taken before a reset clears the counters */
     int32_t* episode_length_out;   /* out */
     int32_t* n_done;               /* out: one int32, number of envs with dones != 0 (zeroed by the call) */
+    uint8_t* executed;             /* out, optional (may be NULL): !invalid — info["cyber_step_executed"] (mcbs_attacker_wrapper_finish only) */
 } mcbs_wrapper_buffers;
 int  mcbs_attacker_wrapper_post(mcbs_batch*, const mcbs_wrapper_buffers* w, float invalid_action_reward_modifier, int32_t max_timesteps,
                                 void* stream);
@@ -424,6 +425,20 @@ typedef struct mcbs_row_copies {
     size_t      row_bytes[8];
 } mcbs_row_copies;
 int  mcbs_copy_rows_masked(mcbs_batch*, const mcbs_row_copies* copies, const uint8_t* env_mask, void* stream);
+
+/* Everything an auto-resetting attacker wrapper does after the environment step, in ONE launch: mcbs_attacker_wrapper_post for every env
+ * (n_done may be NULL here: nothing is counted; `executed` is written if given), then for the envs whose `dones` it has just set — what SB3's DummyVecEnv.step_wait does
+ * with an env that reports done (baseline_marlon_agent.py:100-167 runs the wrappers under it) —
+ *   keep:   dst[i][e] = src[i][e]        the episode's last observation (infos[e]["terminal_observation"]),
+ *   the env is reset (mcbs_reset for it: reset image, episode counter + 1),
+ *   fresh:  dst[i][e] = src[i][0]        the reset observation: `src` arrays hold ONE row, the observation of a freshly reset env
+ *                                        (every env resets to the same state, so the wrapper keeps row 0 of its first observation),
+ *   the env's digest (mcbs_mask_logits) becomes that of a freshly reset env, and its wrapper counters go back to zero (wrapper_clear).
+ * keep / fresh may be NULL (or n = 0); with auto_reset == 0 only the bookkeeping runs.  The batch must have been reset as a whole
+ * (mcbs_reset with a NULL mask) and observed once before the first call, so that the library holds a reset env's digest:
+ * MCBS_ESTATE otherwise.  Replaces five launches and a memset of the round-2 wrapper step. */
+int  mcbs_attacker_wrapper_finish(mcbs_batch*, const mcbs_wrapper_buffers* w, float invalid_action_reward_modifier, int32_t max_timesteps,
+                                  int32_t auto_reset, const mcbs_row_copies* keep, const mcbs_row_copies* fresh, void* stream);
 
 /* The reward shaping of marlon's DefenderEnvWrapper.step (defend_wrapper.py:228-282) around mcbs_defender_step, for every env in one
  * launch and in the wrapper's own order of double-precision operations: invalid-action penalty, minus the attacker's last environment

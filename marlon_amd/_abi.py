@@ -40,7 +40,7 @@ class WrapperBuffers(C.Structure):
     """mcbs_wrapper_buffers (include/mcbs.h): device arrays of AttackerEnvWrapper's per-env bookkeeping"""
     _fields_ = [(n, C.c_void_p) for n in ("invalid", "reward", "terminated", "timesteps", "valid_action_count", "invalid_action_count",
                                           "episode_returns", "last_cyber_reward", "has_cyber_reward", "rewards", "truncated", "dones",
-                                          "episode_return_out", "episode_length_out", "n_done")]
+                                          "episode_return_out", "episode_length_out", "n_done", "executed")]
 
 
 class DefenderWrapperBuffers(C.Structure):

@@ -74,6 +74,8 @@ struct mcbs_batch {
     uint8_t* arena = nullptr;       // every per-env column + bodies + init body, one allocation
     size_t arena_bytes = 0;
     ObsDigest* digest = nullptr;
+    ObsDigest* reset_digest = nullptr;   // the digest of a freshly reset env, captured by the first observation after a whole-batch reset
+    bool all_fresh = true, reset_digest_ok = false;
     const double* tape = nullptr;
     uint32_t tape_dps = 0;
     unsigned long long* stamps = nullptr;   // diagnostic builds: device buffer [waves][8]
@@ -368,6 +370,7 @@ extern "C" int mcbs_batch_create(const mcbs_topology* topo, const mcbs_batch_cfg
     const size_t o_ring = has_def ? take(8ull * 16 * S.WT * E) : 0;
     const size_t o_init = take(S.body_stride);
     const size_t o_digest = take(sizeof(ObsDigest) * (size_t)E);
+    const size_t o_rdigest = take(sizeof(ObsDigest));
     const size_t o_body = take((size_t)S.body_stride * E + 64);   // + 64: packed batches fetch a fixed 64 bytes of rows per env
     b->arena_bytes = off;
 
@@ -383,6 +386,7 @@ extern "C" int mcbs_batch_create(const mcbs_topology* topo, const mcbs_batch_cfg
     S.ring = has_def ? reinterpret_cast<uint64_t*>(a + o_ring) : nullptr;
     S.body = a + o_body; S.init_body = a + o_init;
     b->digest = reinterpret_cast<ObsDigest*>(a + o_digest);
+    b->reset_digest = reinterpret_cast<ObsDigest*>(a + o_rdigest);
     b->T.base = topo->dev;
     b->T.hot = topo->hot_dev;
 
@@ -483,6 +487,7 @@ static int launch_ok(const char* what) {
 extern "C" int mcbs_reset(mcbs_batch* b, const uint8_t* env_mask, void* stream) {
     if (!b) return fail(MCBS_EINVAL, "null batch");
     hipLaunchKernelGGL(reset_kernel, dim3((b->S.E + 127) / 128), dim3(128), 0, (hipStream_t)stream, b->S, b->T, env_mask, 1);
+    if (!env_mask) b->all_fresh = true;
     return launch_ok("reset");
 }
 
@@ -571,6 +576,7 @@ static void launch_step_nw(mcbs_batch* b, const StepIO& io, hipStream_t st, cons
 
 template <int PHASE, bool MANY = false>
 static int launch_step(mcbs_batch* b, const StepIO& io, hipStream_t st, const char* what, const RollArgs& roll = RollArgs{}) {
+    b->all_fresh = false;
     if (b->S.packed) launch_step_nw<PHASE, 0, MANY>(b, io, st, roll);       // WT 0: packed sets (one word of registers each)
     else if (b->S.WT == 1) launch_step_nw<PHASE, 1, MANY>(b, io, st, roll);
     else if (b->S.WT == 2) launch_step_nw<PHASE, 2, MANY>(b, io, st, roll);
@@ -630,7 +636,22 @@ extern "C" int mcbs_rollout_random(mcbs_batch* b, int32_t valid, uint64_t seed, 
 
 static int launch_masks(mcbs_batch* b, const mcbs_obs_buffers* o, hipStream_t st, const uint8_t* env_mask, bool masks_only);
 
+// The first whole-batch observation after a whole-batch reset also keeps env 0's digest as "the digest of a freshly reset env"
+// (mcbs_attacker_wrapper_finish hands it to the envs it resets): one 64-byte device copy, once per batch.
+static int capture_reset_digest(mcbs_batch* b, hipStream_t st, bool whole_batch) {
+    if (!whole_batch || !b->all_fresh || b->reset_digest_ok) return MCBS_OK;
+    HIP_TRY(hipMemcpyAsync(b->reset_digest, b->digest, sizeof(ObsDigest), hipMemcpyDeviceToDevice, st));
+    b->reset_digest_ok = true;
+    return MCBS_OK;
+}
+
+static int launch_obs_inner(mcbs_batch* b, const mcbs_obs_buffers* o, hipStream_t st, bool masks_only, const uint8_t* env_mask);
 static int launch_obs(mcbs_batch* b, const mcbs_obs_buffers* o, hipStream_t st, bool masks_only = false, const uint8_t* env_mask = nullptr) {
+    const int rc = launch_obs_inner(b, o, st, masks_only, env_mask);
+    return rc ? rc : capture_reset_digest(b, st, !masks_only && !env_mask);
+}
+
+static int launch_obs_inner(mcbs_batch* b, const mcbs_obs_buffers* o, hipStream_t st, bool masks_only, const uint8_t* env_mask) {
     ObsIO O{};
     O.masks_only = masks_only ? 1u : 0u;
     O.env_mask = env_mask;
@@ -774,7 +795,8 @@ extern "C" int mcbs_step_observe(mcbs_batch* b, const int32_t* actions, float* r
 extern "C" int mcbs_attacker_wrapper_post(mcbs_batch* b, const mcbs_wrapper_buffers* w, float modifier, int32_t max_timesteps, void* stream) {
     if (!b || !w) return fail(MCBS_EINVAL, "null argument");
     const void* const* p = reinterpret_cast<const void* const*>(w);
-    for (size_t i = 0; i < sizeof(*w) / sizeof(void*); ++i) if (!p[i]) return fail(MCBS_EINVAL, "mcbs_wrapper_buffers: every array is required");
+    for (size_t i = 0; i + 1 < sizeof(*w) / sizeof(void*); ++i)          // `executed` (the last member) is not written by this call
+        if (!p[i]) return fail(MCBS_EINVAL, "mcbs_wrapper_buffers: every array but `executed` is required");
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipMemsetAsync(w->n_done, 0, sizeof(int32_t), st));
     hipLaunchKernelGGL(wrapper_post_kernel, dim3((b->S.E + 255) / 256), dim3(256), 0, st, b->S.E, *w, modifier, max_timesteps);
@@ -796,6 +818,26 @@ extern "C" int mcbs_copy_rows_masked(mcbs_batch* b, const mcbs_row_copies* copie
     const uint32_t waves = (b->S.E + 63u) / 64u;
     hipLaunchKernelGGL(copy_rows_masked_kernel, dim3((waves + 3u) / 4u), dim3(256), 0, (hipStream_t)stream, *copies, env_mask, b->S.E);
     return launch_ok("copy rows");
+}
+
+extern "C" int mcbs_attacker_wrapper_finish(mcbs_batch* b, const mcbs_wrapper_buffers* w, float modifier, int32_t max_timesteps, int32_t auto_reset,
+                                            const mcbs_row_copies* keep, const mcbs_row_copies* fresh, void* stream) {
+    if (!b || !w) return fail(MCBS_EINVAL, "null argument");
+    const void* const* p = reinterpret_cast<const void* const*>(w);
+    for (size_t i = 0; i + 2 < sizeof(*w) / sizeof(void*); ++i)          // n_done and executed (the last two members) may be NULL
+        if (!p[i]) return fail(MCBS_EINVAL, "mcbs_wrapper_buffers: every array but n_done and executed is required");
+    mcbs_row_copies none{};
+    const mcbs_row_copies* rc[2] = {keep ? keep : &none, fresh ? fresh : &none};
+    for (const mcbs_row_copies* c : rc) {
+        if (c->n > 8) return fail(MCBS_EINVAL, "at most eight arrays per list");
+        for (uint32_t i = 0; i < c->n; ++i) if (!c->src[i] || !c->dst[i]) return fail(MCBS_EINVAL, "null array");
+    }
+    if (auto_reset && !b->reset_digest_ok)
+        return fail(MCBS_ESTATE, "no reset observation yet: reset the whole batch (mcbs_reset, NULL mask) and observe it once before the first call");
+    b->all_fresh = false;
+    hipLaunchKernelGGL(wrapper_finish_kernel, dim3((b->S.E + 255) / 256), dim3(256), 0, (hipStream_t)stream, b->S, b->T, *w, modifier, max_timesteps,
+                       (int)auto_reset, *rc[0], *rc[1], b->digest, b->reset_digest);
+    return launch_ok("wrapper finish");
 }
 
 extern "C" int mcbs_defender_wrapper_post(mcbs_batch* b, const mcbs_defender_wrapper_buffers* w, const mcbs_defender_wrapper_cfg* cfg, void* stream) {
@@ -895,6 +937,7 @@ extern "C" int mcbs_defender_step(mcbs_batch* b, const int64_t* actions, uint8_t
     if (!b || !actions) return fail(MCBS_EINVAL, "null argument");
     if (b->cfg.defender_kind != MCBS_DEFENDER_EXTERNAL) return fail(MCBS_ESTATE, "batch was not created with MCBS_DEFENDER_EXTERNAL");
     hipStream_t st = (hipStream_t)stream;
+    b->all_fresh = false;
     const dim3 grid((b->S.E + 127) / 128), block(128);
     if (b->S.WT == 1) hipLaunchKernelGGL((defender_kernel<1>), grid, block, 0, st, b->S, b->T, b->C_dev, actions, valid, availability, evicted);
     else if (b->S.WT == 2) hipLaunchKernelGGL((defender_kernel<2>), grid, block, 0, st, b->S, b->T, b->C_dev, actions, valid, availability, evicted);
@@ -1052,6 +1095,7 @@ extern "C" int mcbs_set_state(mcbs_batch* b, const void* host_buf, size_t nbytes
         ep[e] = sh->episode;
     }
     HIP_TRY(hipMemcpy(b->arena, host.data(), b->arena_bytes, hipMemcpyHostToDevice));
+    b->all_fresh = false;
     return MCBS_OK;
 }
 

@@ -156,6 +156,69 @@ __global__ __launch_bounds__(256) void copy_rows_masked_kernel(mcbs_row_copies r
     }
 }
 
+// mcbs_attacker_wrapper_finish: wrapper_post for every env, then — for the envs it has just flagged done — terminal observation kept,
+// env reset (reset_kernel's work), reset observation and digest put in place, counters cleared (wrapper_clear): one wavefront per 64
+// envs, the flagged ones handled one after the other by all 64 lanes.
+__device__ __forceinline__ void copy_row_wave(const uint8_t* s, uint8_t* d, size_t nb, uint32_t lane) {
+    if (((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(d)) & 15u) == 0) {
+        const size_t nv = nb >> 4;
+        for (size_t i = lane; i < nv; i += 64u) reinterpret_cast<uint4*>(d)[i] = reinterpret_cast<const uint4*>(s)[i];
+        for (size_t i = (nv << 4) + lane; i < nb; i += 64u) d[i] = s[i];
+    } else {
+        for (size_t i = lane; i < nb; i += 64u) d[i] = s[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void wrapper_finish_kernel(DevState S, Topo T, mcbs_wrapper_buffers w, float modifier, int32_t max_timesteps,
+                                                            int auto_reset, mcbs_row_copies keep, mcbs_row_copies fresh, ObsDigest* digest,
+                                                            const ObsDigest* reset_digest) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u;
+    bool done = false;
+    if (e < S.E) {                                       // wrapper_post_kernel, word for word
+        const bool invalid = w.invalid[e] != 0;
+        const float r = w.reward[e];
+        const int32_t t = w.timesteps[e] + 1;
+        const float shaped = r + (invalid ? modifier : 0.0f);
+        const double ret = w.episode_returns[e] + (double)shaped;
+        const bool trunc = t >= max_timesteps;
+        done = (w.terminated[e] != 0) || trunc;
+        const bool clear = done && auto_reset;
+        w.timesteps[e] = clear ? 0 : t;
+        const int64_t nv = w.valid_action_count[e] + (invalid ? 0 : 1), ni = w.invalid_action_count[e] + (invalid ? 1 : 0);
+        w.valid_action_count[e] = clear ? 0 : nv;
+        w.invalid_action_count[e] = clear ? 0 : ni;
+        w.episode_returns[e] = clear ? 0.0 : ret;
+        w.last_cyber_reward[e] = r;
+        w.has_cyber_reward[e] = clear ? 0 : 1;
+        w.rewards[e] = shaped;
+        w.truncated[e] = trunc ? 1 : 0;
+        w.dones[e] = done ? 1 : 0;
+        w.episode_return_out[e] = ret;
+        w.episode_length_out[e] = t;
+        if (w.executed) w.executed[e] = invalid ? 0 : 1;
+    }
+    uint64_t m = auto_reset ? __ballot(done) : 0ull;
+    if (!m) return;
+    const uint32_t wave_base = e - lane;
+    while (m) {
+        const uint32_t r = wave_base + (uint32_t)__builtin_ctzll(m);
+        m &= m - 1;
+        for (uint32_t f = 0; f < keep.n; ++f) {          // the episode's last observation (its loads have landed before any store below is issued)
+            const size_t nb = keep.row_bytes[f];
+            copy_row_wave(static_cast<const uint8_t*>(keep.src[f]) + (size_t)r * nb, static_cast<uint8_t*>(keep.dst[f]) + (size_t)r * nb, nb, lane);
+        }
+        for (uint32_t f = 0; f < fresh.n; ++f) {         // the observation of a freshly reset env
+            const size_t nb = fresh.row_bytes[f];
+            copy_row_wave(static_cast<const uint8_t*>(fresh.src[f]), static_cast<uint8_t*>(fresh.dst[f]) + (size_t)r * nb, nb, lane);
+        }
+        uint8_t* dst = S.body + (size_t)r * S.body_stride;
+        for (uint32_t off = lane * 16u; off < S.body_stride; off += 64u * 16u)
+            *reinterpret_cast<uint4*>(dst + off) = *reinterpret_cast<const uint4*>(S.init_body + off);
+        if (lane < 4u) reinterpret_cast<uint4*>(digest + r)[lane] = reinterpret_cast<const uint4*>(reset_digest)[lane];
+    }
+    if (done) reset_header(S, T, e, S.episode[e] + 1u);
+}
+
 // DefenderEnvWrapper.step's reward shaping (defend_wrapper.py:228-282), same order of fp64 operations as the host version it replaces
 __global__ __launch_bounds__(256) void defender_wrapper_post_kernel(uint32_t E, mcbs_defender_wrapper_buffers w, mcbs_defender_wrapper_cfg c) {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;

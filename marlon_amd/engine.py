@@ -23,7 +23,7 @@ EXPORTS = [
     "mcbs_last_error", "mcbs_abi_version", "mcbs_topology_create", "mcbs_topology_destroy", "mcbs_batch_create",
     "mcbs_batch_destroy", "mcbs_reset", "mcbs_step", "mcbs_step_observe", "mcbs_observe", "mcbs_observe_masked", "mcbs_action_mask", "mcbs_step_info",
     "mcbs_step_many", "mcbs_rollout_random", "mcbs_attacker_wrapper_post", "mcbs_attacker_wrapper_clear", "mcbs_defender_wrapper_post", "mcbs_sample_actions", "mcbs_decode_attacker_actions", "mcbs_defender_step", "mcbs_defender_observe", "mcbs_set_draw_tape", "mcbs_state_record_bytes", "mcbs_get_state", "mcbs_set_state",
-    "mcbs_timing_enable", "mcbs_timing_read", "mcbs_mask_logits", "mcbs_discrete_action_count", "mcbs_copy_rows_masked",
+    "mcbs_timing_enable", "mcbs_timing_read", "mcbs_mask_logits", "mcbs_discrete_action_count", "mcbs_copy_rows_masked", "mcbs_attacker_wrapper_finish",
 ]
 
 _lib = None
@@ -80,6 +80,7 @@ def load_library(path: Optional[str] = None):
     lib.mcbs_discrete_action_count.argtypes = [C.c_void_p]
     lib.mcbs_mask_logits.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_size_t, C.c_float, C.c_void_p]
     lib.mcbs_copy_rows_masked.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.mcbs_attacker_wrapper_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.mcbs_timing_enable.argtypes = [C.c_void_p, C.c_int32]
     lib.mcbs_timing_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     for name in EXPORTS:
@@ -258,6 +259,34 @@ class BatchEngine:
                 raise ValueError("copy_rows_masked needs contiguous [E, ...] tensors of the same shape and dtype")
             rc.src[i], rc.dst[i], rc.row_bytes[i] = src.data_ptr(), dst.data_ptr(), src[0].numel() * src.element_size()
         _check(self.lib, self.lib.mcbs_copy_rows_masked(self._h, C.byref(rc), env_mask.data_ptr(), self._stream()), "mcbs_copy_rows_masked")
+
+    def _row_copies(self, pairs, one_row_src: bool):
+        from ._abi import RowCopies
+        if len(pairs) > 8:
+            raise ValueError("at most eight (src, dst) pairs per list")
+        rc = RowCopies()
+        rc.n = len(pairs)
+        for i, (src, dst) in enumerate(pairs):
+            rows = 1 if one_row_src else self.E
+            if src.shape[1:] != dst.shape[1:] or src.dtype != dst.dtype or not (src.is_contiguous() and dst.is_contiguous()) or \
+                    src.shape[0] != rows or dst.shape[0] != self.E:
+                raise ValueError("row copies need contiguous tensors of the same row shape and dtype ([E, ...]; reset rows: [1, ...])")
+            rc.src[i], rc.dst[i], rc.row_bytes[i] = src.data_ptr(), dst.data_ptr(), dst[0].numel() * dst.element_size()
+        return rc
+
+    def wrapper_finish(self, bufs, modifier: float, max_timesteps: int, auto_reset: bool, keep=(), fresh=()) -> None:
+        """mcbs_attacker_wrapper_finish: the wrapper's bookkeeping and — for the envs it flags done — terminal observation (`keep`:
+        (obs, terminal) pairs), env reset, reset observation (`fresh`: ([1, ...] row of a freshly reset env, obs) pairs) and cleared
+        counters, all in one launch.  `keep` / `fresh` may be argument blocks built once with `row_copies()`."""
+        from ._abi import RowCopies
+        k = keep if isinstance(keep, RowCopies) else self._row_copies(list(keep), False)
+        f = fresh if isinstance(fresh, RowCopies) else self._row_copies(list(fresh), True)
+        _check(self.lib, self.lib.mcbs_attacker_wrapper_finish(self._h, C.byref(bufs), float(modifier), int(max_timesteps), int(bool(auto_reset)),
+                                                               C.byref(k), C.byref(f), self._stream()), "mcbs_attacker_wrapper_finish")
+
+    def row_copies(self, pairs, one_row_src: bool = False):
+        """Argument block (_abi.RowCopies) for wrapper_finish, built once and reused across steps."""
+        return self._row_copies(list(pairs), one_row_src)
 
     def wrapper_clear(self, bufs) -> None:
         _check(self.lib, self.lib.mcbs_attacker_wrapper_clear(self._h, C.byref(bufs), self._stream()), "mcbs_attacker_wrapper_clear")

@@ -81,14 +81,14 @@ class AttackerVecEnv:
         self.episode_returns = t.zeros(n_envs, dtype=t.float64, device=dev)
         self.last_cyber_reward = t.zeros(n_envs, dtype=t.float32, device=dev)
         self.has_cyber_reward = t.zeros(n_envs, dtype=t.bool, device=dev)    # AttackerEnvWrapper.cyber_rewards is non-empty
-        # outputs of the fused bookkeeping launch (mcbs_attacker_wrapper_post) and its argument block
+        # outputs of the fused bookkeeping / auto-reset launch (mcbs_attacker_wrapper_finish) and its argument blocks
         self._rewards = t.zeros(n_envs, dtype=t.float32, device=dev)
         self._truncated = t.zeros(n_envs, dtype=t.uint8, device=dev)
         self._dones = t.zeros(n_envs, dtype=t.uint8, device=dev)
         self._ret_out = t.zeros(n_envs, dtype=t.float64, device=dev)
         self._len_out = t.zeros(n_envs, dtype=t.int32, device=dev)
         self._n_done = t.zeros(1, dtype=t.int32, device=dev)
-        self._wb = None
+        self._wb = self._keep = self._fresh = self._reset_rows = None
         # use_graph: the whole wrapper step (decode, environment step + observation, bookkeeping, terminal-observation copy, reset and reset
         # observation of the envs that ended) is captured into ONE hipGraph on the first call and replayed afterwards: the step has no
         # host round trip, so what remains on the host is one graph launch.  Outputs are then the wrapper's own buffers (overwritten
@@ -98,6 +98,8 @@ class AttackerVecEnv:
             raise ValueError("use_graph replays fixed kernel arguments: it cannot be combined with a defender draw tape (rng_kind=TAPE)")
         self._graph = None
         self._act_in = t.zeros((n_envs,) if self.discrete else (n_envs, 10), dtype=t.int64, device=dev)
+        self._executed = t.zeros(n_envs, dtype=t.bool, device=dev)
+        self._graph_out = None
         self.reset()
 
     # -- observation plumbing --
@@ -140,12 +142,20 @@ class AttackerVecEnv:
     def reset(self):
         self.engine.reset()
         self.engine.observe(self._obs)
+        if self._reset_rows is None:
+            self._reset_rows = {k: v[0:1].clone() for k, v in self._obs.items()}
         self.timesteps.zero_()
         self.valid_action_count.zero_()
         self.invalid_action_count.zero_()
         self.episode_returns.zero_()
         self.has_cyber_reward.zero_()
         return self.observation
+
+    @property
+    def action_buffer(self):
+        """use_graph: the int64 device tensor the captured step reads its actions from ([E] Discrete, [E, 10] MultiDiscrete).  A policy
+        that writes into it and calls `step(venv.action_buffer)` saves the copy."""
+        return self._act_in
 
     def _step_device(self, actions) -> None:
         """Everything a wrapper step does on the device, enqueued on the current stream without any host round trip."""
@@ -161,23 +171,21 @@ class AttackerVecEnv:
             self._wb = WrapperBuffers(*[x.data_ptr() for x in (
                 self._invalid, reward, terminated, self.timesteps, self.valid_action_count, self.invalid_action_count, self.episode_returns,
                 self.last_cyber_reward, self.has_cyber_reward, self._rewards, self._truncated, self._dones, self._ret_out, self._len_out,
-                self._n_done)])
-        self.engine.wrapper_post(self._wb, self.invalid_action_reward_modifier, self.max_timesteps)
-        # what DummyVecEnv.step_wait does for an env that reports done — keep its last observation, reset it, return the reset
-        # observation — for the envs flagged in `dones`, as mask-scanning launches (a few microseconds when no env ended).  Eagerly,
-        # one host read of the done counter skips them on the (common) steps where nothing ended; a captured step always carries them.
-        if self.auto_reset and (self.use_graph or int(self._n_done.item())):
-            self.engine.copy_rows_masked([(self._obs[k], self._terminal[k]) for k in self._obs], self._dones)
-            self.engine.reset(self._dones)
-            self.engine.observe(self._obs, env_mask=self._dones)   # the others keep their observation
-            self.engine.wrapper_clear(self._wb)
+                self._n_done, self._executed)])
+            self._keep = self.engine.row_copies([(self._obs[k], self._terminal[k]) for k in self._obs])
+            self._fresh = self.engine.row_copies([(self._reset_rows[k], self._obs[k]) for k in self._obs], one_row_src=True)
+        # ... and what DummyVecEnv.step_wait does for an env that reports done — keep its last observation, reset it, return the reset
+        # observation — for the envs the bookkeeping has just flagged, in the same launch (mcbs_attacker_wrapper_finish): no host read
+        # of a done counter, eagerly or captured.  Every env resets to the same state, so the reset observation is row 0 of reset()'s.
+        self.engine.wrapper_finish(self._wb, self.invalid_action_reward_modifier, self.max_timesteps, self.auto_reset, self._keep, self._fresh)
 
     def step(self, actions):
         """-> (observation dict, rewards f32 [E], terminated u8 [E], truncated u8 [E], info dict of tensors)."""
         t = self.torch
         if self.use_graph:
-            a = actions if isinstance(actions, t.Tensor) else t.as_tensor(np.asarray(actions))
-            self._act_in.copy_(a.to(device=self.engine.device).reshape(self._act_in.shape), non_blocking=True)
+            if actions is not self._act_in:                    # a policy may write its actions straight into `action_buffer`: no copy then
+                a = actions if isinstance(actions, t.Tensor) else t.as_tensor(np.asarray(actions))
+                self._act_in.copy_(a.to(device=self.engine.device).reshape(self._act_in.shape), non_blocking=True)
             if self._graph is None:
                 self._step_device(self._act_in)            # this step runs eagerly (it also creates the argument blocks) ...
                 t.cuda.synchronize(self.engine.device)
@@ -192,15 +200,16 @@ class AttackerVecEnv:
                 # ... and is then captured for the steps to come (capturing executes nothing)
             else:
                 self._graph.replay()
-            invalid = self._invalid.view(t.bool)
-            info = {"invalid_action": invalid, "cyber_step_executed": ~invalid,
-                    "network_availability": self.engine.info["network_availability"], "step_count": self.engine.info["step_count"],
-                    "episode_return": self._ret_out, "episode_length": self._len_out}
-            return self.observation, self._rewards, self.engine.terminated, self._truncated, info
+            if self._graph_out is None:                        # the same persistent buffers every step: built once
+                self._graph_out = (self.observation, self._rewards, self.engine.terminated, self._truncated,
+                                   {"invalid_action": self._invalid.view(t.bool), "cyber_step_executed": self._executed,
+                                    "network_availability": self.engine.info["network_availability"], "step_count": self.engine.info["step_count"],
+                                    "episode_return": self._ret_out, "episode_length": self._len_out})
+            return self._graph_out
         self._step_device(actions)
         invalid = self._invalid.view(t.bool)
         rewards, truncated, terminated = self._rewards.clone(), self._truncated.clone(), self.engine.terminated.clone()
-        info = {"invalid_action": invalid.clone(), "cyber_step_executed": ~invalid,
+        info = {"invalid_action": invalid.clone(), "cyber_step_executed": self._executed.clone(),
                 "network_availability": self.engine.info["network_availability"], "step_count": self.engine.info["step_count"],
                 "episode_return": self._ret_out.clone(), "episode_length": self._len_out.clone()}
         return self.observation, rewards, terminated, truncated, info

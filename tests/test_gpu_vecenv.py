@@ -295,3 +295,65 @@ def test_graph_replayed_defender_turn_equals_eager():
             assert torch.equal(o1[k], o2[k]), f"defender step {t} obs {k}"
     assert bool((i1["network_availability"] < 1.0).any())            # re-imaging happened: the turns were not trivial
     a1.close(); a2.close()
+
+
+@pytest.mark.parametrize("materialize_masks", [False, True])
+def test_wrapper_finish_equals_the_separate_launches_it_replaces(materialize_masks):
+    """mcbs_attacker_wrapper_finish (bookkeeping + terminal observation + reset + reset observation + cleared counters in one launch)
+    against the five launches it replaces, which stay exported: mcbs_attacker_wrapper_post, mcbs_copy_rows_masked, mcbs_reset(mask),
+    mcbs_observe_masked, mcbs_attacker_wrapper_clear — same actions, short episodes (truncation at 9 steps), every buffer compared
+    after every step, the digest through mcbs_mask_logits."""
+    import torch
+    from marlon_amd import cyberbattle_env as ce
+    from marlon_amd._abi import WrapperBuffers
+    from marlon_amd.samples import toy_ctf
+    from marlon_amd.wrappers import AttackerVecEnv
+    E = 1024
+
+    def mk():
+        return AttackerVecEnv(toy_ctf.new_environment(), E, maximum_node_count=12, maximum_total_credentials=10,
+                              attacker_goal=ce.AttackerGoal(own_atleast=3), max_timesteps=9, discrete=True, materialize_masks=materialize_masks,
+                              defender_agent=ce.ScanAndReimageCompromisedMachines(0.6, 2, 5), seed=11)
+    new, old = mk(), mk()
+    n_done = torch.zeros(1, dtype=torch.int32, device=old.engine.device)
+
+    def old_step(actions):                                  # round 2's _step_device, launch for launch
+        eng = old.engine
+        eng.decode_attacker_actions(discrete=actions, actions_out=old._rows, invalid_out=old._invalid)
+        reward, terminated = eng.step_observe(old._rows, old._obs)
+        wb = WrapperBuffers(*[x.data_ptr() for x in (
+            old._invalid, reward, terminated, old.timesteps, old.valid_action_count, old.invalid_action_count, old.episode_returns,
+            old.last_cyber_reward, old.has_cyber_reward, old._rewards, old._truncated, old._dones, old._ret_out, old._len_out, n_done)], None)
+        eng.wrapper_post(wb, old.invalid_action_reward_modifier, old.max_timesteps)
+        eng.copy_rows_masked([(old._obs[k], old._terminal[k]) for k in old._obs], old._dones)
+        eng.reset(old._dones)
+        eng.observe(old._obs, env_mask=old._dones)
+        eng.wrapper_clear(wb)
+    g = torch.Generator(device=new.engine.device).manual_seed(3)
+    ended = 0
+    for t in range(40):
+        m = new.action_masks() if materialize_masks else None
+        if m is None:                                       # sample from the masks the digest stands for
+            logits = torch.rand((E, new.discrete_n), generator=g, device=new.engine.device)
+            actions = new.mask_logits(logits, fill=-1.0).argmax(dim=1)
+        else:
+            actions = torch.where(m, torch.rand(m.shape, generator=g, device=m.device), torch.full((1,), -1.0, device=m.device)).argmax(dim=1)
+        if t % 6 == 5:
+            actions[::7] = new.discrete_n - 1               # intercepted actions
+        new.step(actions)
+        old_step(actions)
+        for name in ("_rewards", "_truncated", "_dones", "_ret_out", "_len_out", "_invalid", "timesteps", "valid_action_count", "invalid_action_count",
+                     "episode_returns", "last_cyber_reward", "has_cyber_reward"):
+            assert torch.equal(getattr(new, name), getattr(old, name)), f"step {t}: {name}"
+        assert torch.equal(new._executed, old._invalid == 0), f"step {t}: executed"
+        assert int(n_done) == int(new._dones.sum())
+        ended += int(n_done)
+        for k in new._obs:
+            assert torch.equal(new._obs[k], old._obs[k]), f"step {t}: observation {k}"
+            assert torch.equal(new._terminal[k], old._terminal[k]), f"step {t}: terminal observation {k}"
+        probe = torch.rand((E, new.discrete_n), generator=g, device=new.engine.device)
+        assert torch.equal(new.mask_logits(probe.clone(), fill=-1.0), old.mask_logits(probe.clone(), fill=-1.0)), f"step {t}: digest"
+        for x, y in zip(new.engine.get_state(), old.engine.get_state()):
+            np.testing.assert_array_equal(x, y, err_msg=f"step {t}: environment state")
+    assert ended >= 3 * E                                   # every env was reset inside the fused launch several times
+    new.close(); old.close()

@@ -39,11 +39,31 @@ if what == "wrapper":
     for a in acts[:5]:
         venv.step(a)
     torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    e0.record()
     for a in acts[5:]:
         venv.step(a)
+    e1.record()
+    t1 = time.perf_counter()                                                  # everything is enqueued: the host's share
     torch.cuda.synchronize()
-    print(json.dumps(dict(what=what, workload=name, envs=E, launches=K, us_per_step=(time.perf_counter() - t0) / K * 1e6)))
+    t2 = time.perf_counter()
+    out = dict(what=what, workload=name, envs=E, launches=K, us_per_step=(t2 - t0) / K * 1e6, host_enqueue_us_per_step=(t1 - t0) / K * 1e6,
+               device_us_per_step=e0.elapsed_time(e1) * 1e3 / K)
+    if venv.use_graph:                      # the policy writes its actions into the wrapper's own buffer: no copy in front of the replay
+        buf = venv.action_buffer
+        buf.copy_(acts[-1])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(K):
+            venv.step(buf)
+        e1.record()
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        out.update(in_place_us_per_step=(time.perf_counter() - t0) / K * 1e6, in_place_host_enqueue_us=(t1 - t0) / K * 1e6,
+                   in_place_device_us=e0.elapsed_time(e1) * 1e3 / K)
+    print(json.dumps(out))
     venv.close()
     raise SystemExit(0)
 ring = W.record_ring(name, K if what == "step" else 40)
