@@ -426,6 +426,13 @@ typedef struct mcbs_row_copies {
 } mcbs_row_copies;
 int  mcbs_copy_rows_masked(mcbs_batch*, const mcbs_row_copies* copies, const uint8_t* env_mask, void* stream);
 
+/* One whole step of marlon's attacker wrappers for the batch — AttackerEnvWrapper.step (attack_wrapper.py:255-372) under
+ * MaskedDiscreteAttackerWrapper (action_masking.py:112-142) under SB3's DummyVecEnv — enqueued by ONE call:
+ *   mcbs_decode_attacker_actions (exactly one of multidiscrete [n_envs, 10] / discrete [n_envs]; `decoded` [n_envs, 5] receives the rows,
+ *   w->invalid the interception flags), mcbs_step_observe (w->reward and w->terminated receive the environment's reward and done flags:
+ *   the three `in` arrays of mcbs_wrapper_buffers are written by this call), mcbs_attacker_wrapper_finish.
+ * Stream-ordered, no host synchronisation, hipGraph-capturable (five launches today). */
+
 /* Everything an auto-resetting attacker wrapper does after the environment step, in ONE launch: mcbs_attacker_wrapper_post for every env
  * (n_done may be NULL here: nothing is counted; `executed` is written if given), then for the envs whose `dones` it has just set — what SB3's DummyVecEnv.step_wait does
  * with an env that reports done (baseline_marlon_agent.py:100-167 runs the wrappers under it) —
@@ -437,6 +444,10 @@ int  mcbs_copy_rows_masked(mcbs_batch*, const mcbs_row_copies* copies, const uin
  * keep / fresh may be NULL (or n = 0); with auto_reset == 0 only the bookkeeping runs.  The batch must have been reset as a whole
  * (mcbs_reset with a NULL mask) and observed once before the first call, so that the library holds a reset env's digest:
  * MCBS_ESTATE otherwise.  Replaces five launches and a memset of the round-2 wrapper step. */
+int  mcbs_attacker_wrapper_step(mcbs_batch*, const int64_t* multidiscrete, const int64_t* discrete, int32_t* decoded,
+                                const mcbs_info_buffers* info, const mcbs_obs_buffers* obs, const mcbs_wrapper_buffers* w,
+                                float invalid_action_reward_modifier, int32_t max_timesteps, int32_t auto_reset,
+                                const mcbs_row_copies* keep, const mcbs_row_copies* fresh, void* stream);
 int  mcbs_attacker_wrapper_finish(mcbs_batch*, const mcbs_wrapper_buffers* w, float invalid_action_reward_modifier, int32_t max_timesteps,
                                   int32_t auto_reset, const mcbs_row_copies* keep, const mcbs_row_copies* fresh, void* stream);
 

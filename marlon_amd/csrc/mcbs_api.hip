@@ -840,6 +840,17 @@ extern "C" int mcbs_attacker_wrapper_finish(mcbs_batch* b, const mcbs_wrapper_bu
     return launch_ok("wrapper finish");
 }
 
+extern "C" int mcbs_attacker_wrapper_step(mcbs_batch* b, const int64_t* multidiscrete, const int64_t* discrete, int32_t* decoded,
+                                          const mcbs_info_buffers* info, const mcbs_obs_buffers* obs, const mcbs_wrapper_buffers* w, float modifier,
+                                          int32_t max_timesteps, int32_t auto_reset, const mcbs_row_copies* keep, const mcbs_row_copies* fresh,
+                                          void* stream) {
+    if (!b || !w || !decoded || !obs) return fail(MCBS_EINVAL, "null argument");
+    int rc = mcbs_decode_attacker_actions(b, multidiscrete, discrete, decoded, const_cast<uint8_t*>(w->invalid), stream);
+    if (rc) return rc;
+    if ((rc = mcbs_step_observe(b, decoded, const_cast<float*>(w->reward), const_cast<uint8_t*>(w->terminated), info, obs, stream))) return rc;
+    return mcbs_attacker_wrapper_finish(b, w, modifier, max_timesteps, auto_reset, keep, fresh, stream);
+}
+
 extern "C" int mcbs_defender_wrapper_post(mcbs_batch* b, const mcbs_defender_wrapper_buffers* w, const mcbs_defender_wrapper_cfg* cfg, void* stream) {
     if (!b || !w || !cfg) return fail(MCBS_EINVAL, "null argument");
     const void* const* p = reinterpret_cast<const void* const*>(w);

@@ -23,7 +23,7 @@ EXPORTS = [
     "mcbs_last_error", "mcbs_abi_version", "mcbs_topology_create", "mcbs_topology_destroy", "mcbs_batch_create",
     "mcbs_batch_destroy", "mcbs_reset", "mcbs_step", "mcbs_step_observe", "mcbs_observe", "mcbs_observe_masked", "mcbs_action_mask", "mcbs_step_info",
     "mcbs_step_many", "mcbs_rollout_random", "mcbs_attacker_wrapper_post", "mcbs_attacker_wrapper_clear", "mcbs_defender_wrapper_post", "mcbs_sample_actions", "mcbs_decode_attacker_actions", "mcbs_defender_step", "mcbs_defender_observe", "mcbs_set_draw_tape", "mcbs_state_record_bytes", "mcbs_get_state", "mcbs_set_state",
-    "mcbs_timing_enable", "mcbs_timing_read", "mcbs_mask_logits", "mcbs_discrete_action_count", "mcbs_copy_rows_masked", "mcbs_attacker_wrapper_finish",
+    "mcbs_timing_enable", "mcbs_timing_read", "mcbs_mask_logits", "mcbs_discrete_action_count", "mcbs_copy_rows_masked", "mcbs_attacker_wrapper_finish", "mcbs_attacker_wrapper_step",
 ]
 
 _lib = None
@@ -80,6 +80,8 @@ def load_library(path: Optional[str] = None):
     lib.mcbs_discrete_action_count.argtypes = [C.c_void_p]
     lib.mcbs_mask_logits.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_size_t, C.c_float, C.c_void_p]
     lib.mcbs_copy_rows_masked.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.mcbs_attacker_wrapper_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int32,
+                                               C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.mcbs_attacker_wrapper_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.mcbs_timing_enable.argtypes = [C.c_void_p, C.c_int32]
     lib.mcbs_timing_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
@@ -283,6 +285,20 @@ class BatchEngine:
         f = fresh if isinstance(fresh, RowCopies) else self._row_copies(list(fresh), True)
         _check(self.lib, self.lib.mcbs_attacker_wrapper_finish(self._h, C.byref(bufs), float(modifier), int(max_timesteps), int(bool(auto_reset)),
                                                                C.byref(k), C.byref(f), self._stream()), "mcbs_attacker_wrapper_finish")
+
+    def wrapper_step(self, actions, discrete: bool, decoded, obs_struct, bufs, modifier: float, max_timesteps: int, auto_reset: bool, keep, fresh) -> None:
+        """mcbs_attacker_wrapper_step: decode, environment step + observation, bookkeeping / auto-reset — one call, five launches.
+        `actions`: int64 device tensor ([E] Discrete or [E, 10] MultiDiscrete); `obs_struct`: obs_struct(obs) built once; `bufs` /
+        `keep` / `fresh`: argument blocks built once (WrapperBuffers, row_copies())."""
+        p = actions.data_ptr()
+        _check(self.lib, self.lib.mcbs_attacker_wrapper_step(self._h, None if discrete else p, p if discrete else None, decoded.data_ptr(),
+                                                             C.byref(self._info_struct), C.byref(obs_struct), C.byref(bufs), float(modifier),
+                                                             int(max_timesteps), int(bool(auto_reset)), C.byref(keep), C.byref(fresh), self._stream()),
+               "mcbs_attacker_wrapper_step")
+
+    def obs_struct(self, obs: dict):
+        """Argument block (_abi.ObsBuffers) for wrapper_step, built once for a set of persistent observation tensors."""
+        return self._obs_struct(obs)
 
     def row_copies(self, pairs, one_row_src: bool = False):
         """Argument block (_abi.RowCopies) for wrapper_finish, built once and reused across steps."""

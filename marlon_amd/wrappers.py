@@ -99,7 +99,7 @@ class AttackerVecEnv:
         self._graph = None
         self._act_in = t.zeros((n_envs,) if self.discrete else (n_envs, 10), dtype=t.int64, device=dev)
         self._executed = t.zeros(n_envs, dtype=t.bool, device=dev)
-        self._graph_out = None
+        self._graph_out = self._terminated_out = None
         self.reset()
 
     # -- observation plumbing --
@@ -158,26 +158,29 @@ class AttackerVecEnv:
         return self._act_in
 
     def _step_device(self, actions) -> None:
-        """Everything a wrapper step does on the device, enqueued on the current stream without any host round trip."""
-        if self.discrete:
-            self.engine.decode_attacker_actions(discrete=actions, actions_out=self._rows, invalid_out=self._invalid)
-        else:
-            self.engine.decode_attacker_actions(multidiscrete=actions, actions_out=self._rows, invalid_out=self._invalid)
-        reward, terminated = self.engine.step_observe(self._rows, self._obs)
-        # counters, reward modifier of intercepted actions (attack_wrapper.py:296,354), truncation (:350-352), episode returns:
-        # one launch for the whole batch
+        """Everything a wrapper step does on the device, enqueued on the current stream by ONE call into the library
+        (mcbs_attacker_wrapper_step) without any host round trip: decode + interception of out-of-range actions, environment step and
+        observation, then — one launch — counters, reward modifier of intercepted actions (attack_wrapper.py:296,354), truncation
+        (:350-352), episode returns and what DummyVecEnv.step_wait does for an env that reports done: keep its last observation, reset
+        it, return the reset observation (every env resets to the same state, so that is row 0 of reset()'s observation)."""
+        t = self.torch
+        a = actions if isinstance(actions, t.Tensor) else t.as_tensor(np.asarray(actions))
+        a = a.to(device=self.engine.device, dtype=t.int64).contiguous()
+        want = (self.num_envs,) if self.discrete else (self.num_envs, 10)
+        if tuple(a.shape) != want:
+            raise ValueError(f"expected actions of shape {want}, got {tuple(a.shape)}")
         if self._wb is None:
             from ._abi import WrapperBuffers
+            eng = self.engine
             self._wb = WrapperBuffers(*[x.data_ptr() for x in (
-                self._invalid, reward, terminated, self.timesteps, self.valid_action_count, self.invalid_action_count, self.episode_returns,
+                self._invalid, eng.reward, eng.terminated if self.use_graph else self._terminated_out, self.timesteps, self.valid_action_count, self.invalid_action_count, self.episode_returns,
                 self.last_cyber_reward, self.has_cyber_reward, self._rewards, self._truncated, self._dones, self._ret_out, self._len_out,
                 self._n_done, self._executed)])
-            self._keep = self.engine.row_copies([(self._obs[k], self._terminal[k]) for k in self._obs])
-            self._fresh = self.engine.row_copies([(self._reset_rows[k], self._obs[k]) for k in self._obs], one_row_src=True)
-        # ... and what DummyVecEnv.step_wait does for an env that reports done — keep its last observation, reset it, return the reset
-        # observation — for the envs the bookkeeping has just flagged, in the same launch (mcbs_attacker_wrapper_finish): no host read
-        # of a done counter, eagerly or captured.  Every env resets to the same state, so the reset observation is row 0 of reset()'s.
-        self.engine.wrapper_finish(self._wb, self.invalid_action_reward_modifier, self.max_timesteps, self.auto_reset, self._keep, self._fresh)
+            self._keep = eng.row_copies([(self._obs[k], self._terminal[k]) for k in self._obs])
+            self._fresh = eng.row_copies([(self._reset_rows[k], self._obs[k]) for k in self._obs], one_row_src=True)
+            self._obs_block = eng.obs_struct(self._obs)
+        self.engine.wrapper_step(a, self.discrete, self._rows, self._obs_block, self._wb, self.invalid_action_reward_modifier, self.max_timesteps,
+                                 self.auto_reset, self._keep, self._fresh)
 
     def step(self, actions):
         """-> (observation dict, rewards f32 [E], terminated u8 [E], truncated u8 [E], info dict of tensors)."""
@@ -206,13 +209,23 @@ class AttackerVecEnv:
                                     "network_availability": self.engine.info["network_availability"], "step_count": self.engine.info["step_count"],
                                     "episode_return": self._ret_out, "episode_length": self._len_out})
             return self._graph_out
+        # eager: every step's outputs are tensors of their own — allocated here and written by the step's launches directly (cloning
+        # persistent buffers afterwards cost seven more launches, more host time than the step itself)
+        E, dev = self.num_envs, self.engine.device
+        self._invalid, self._executed = t.empty(E, dtype=t.uint8, device=dev), t.empty(E, dtype=t.bool, device=dev)
+        self._rewards, self._truncated = t.empty(E, dtype=t.float32, device=dev), t.empty(E, dtype=t.uint8, device=dev)
+        self._ret_out, self._len_out = t.empty(E, dtype=t.float64, device=dev), t.empty(E, dtype=t.int32, device=dev)
+        terminated = t.empty(E, dtype=t.uint8, device=dev)
+        if self._wb is not None:
+            w = self._wb
+            w.invalid, w.executed, w.rewards, w.truncated = self._invalid.data_ptr(), self._executed.data_ptr(), self._rewards.data_ptr(), self._truncated.data_ptr()
+            w.episode_return_out, w.episode_length_out, w.terminated = self._ret_out.data_ptr(), self._len_out.data_ptr(), terminated.data_ptr()
+        self._terminated_out = terminated
         self._step_device(actions)
-        invalid = self._invalid.view(t.bool)
-        rewards, truncated, terminated = self._rewards.clone(), self._truncated.clone(), self.engine.terminated.clone()
-        info = {"invalid_action": invalid.clone(), "cyber_step_executed": self._executed.clone(),
+        info = {"invalid_action": self._invalid.view(t.bool), "cyber_step_executed": self._executed,
                 "network_availability": self.engine.info["network_availability"], "step_count": self.engine.info["step_count"],
-                "episode_return": self._ret_out.clone(), "episode_length": self._len_out.clone()}
-        return self.observation, rewards, terminated, truncated, info
+                "episode_return": self._ret_out, "episode_length": self._len_out}
+        return self.observation, self._rewards, terminated, self._truncated, info
 
     def close(self) -> None:
         self.engine.close()
