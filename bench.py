@@ -540,7 +540,8 @@ def extras_wrapper(K: int = 40):
     """The tier a trainer consumes: one AttackerVecEnv.step (marlon's AttackerEnvWrapper + MaskedDiscreteAttackerWrapper for the whole batch:
     decode, environment step, observation, bookkeeping, auto-reset) per call, 65 536 Chain-10 envs, valid Discrete actions drawn from the
     action masks.  (a) as round 1 measured it: masks materialised, eager launches; (b) no mask written (the policy masks its logits with
-    mcbs_mask_logits) and the whole step replayed as one hipGraph.  Wall time per call on the host, synchronised at both ends."""
+    mcbs_mask_logits), eager launches; (c) the same with the whole step replayed as one hipGraph.  Wall time per call on the host,
+    synchronised at both ends."""
     import torch
     from marlon_amd.samples import chainpattern
     from marlon_amd.wrappers import AttackerVecEnv
@@ -558,7 +559,8 @@ def extras_wrapper(K: int = 40):
     del ref
     torch.cuda.empty_cache()
     out = []
-    for name, opts in (("masks materialised, eager launches", dict()), ("no mask materialised, whole step as one hipGraph", dict(materialize_masks=False, use_graph=True))):
+    for name, opts in (("masks materialised, eager launches", dict()), ("no mask materialised, eager launches", dict(materialize_masks=False)),
+                       ("no mask materialised, whole step as one hipGraph", dict(materialize_masks=False, use_graph=True))):
         env = AttackerVecEnv(chainpattern.new_environment(10), E, **kw, **opts)
         for a in acts[:5]:
             env.step(a)

@@ -498,38 +498,62 @@ __global__ __launch_bounds__(256) void obs_tiny_kernel(DevState S, Topo T, const
         }
         O.scalars[(size_t)e * 7 + j] = v;
     }
+    // One ROW per lane from here on (a leaked-credential record, a cache entry, a node's properties): what a row needs is in the lane's
+    // own registers, a dword-per-lane walk over the flat arrays cost ~12 instructions per dword (LDS read, 64-bit shift, index carry) and
+    // made this kernel issue-bound (16.5 us for 924 B per env; rows: see profiles/round2_notes.md).
     if (O.leaked) {
-        int32_t* out = O.leaked + (size_t)e * O.K * 4;
         const bool have = !blank && kind == MCBS_OUT_LEAKED_CREDENTIALS;
-        for (uint32_t idx = j; idx < O.K * 4u; idx += 16u) {
-            const uint32_t r = idx >> 2, c = idx & 3u;
-            int32_t v = 0;
+        for (uint32_t r = j; r < O.K; r += 16u) {                // (1, cache index, external node index, port) or zeros (env.py:857-869)
+            int32_t* out = O.leaked + ((size_t)e * O.K + r) * 4;
+            int4 v = make_int4(0, 0, 0, 0);
             if (have && r < new_creds) {
-                const uint32_t ci = (n_creds - new_creds + r) & 15u;
-                v = c == 0 ? 1 : c == 1 ? (int32_t)(n_creds - new_creds + r) : c == 2 ? (int32_t)st.cred_ext[ci] : (int32_t)st.cred_port[ci];
+                const uint32_t ci = n_creds - new_creds + r;
+                v = make_int4(1, (int32_t)ci, (int32_t)st.cred_ext[ci & 15u], (int32_t)st.cred_port[ci & 15u]);
             }
-            out[idx] = v;
+            if ((reinterpret_cast<uintptr_t>(out) & 15u) == 0) *reinterpret_cast<int4*>(out) = v;
+            else { out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w; }
         }
     }
     if (O.cache_matrix) {
-        int32_t* out = O.cache_matrix + (size_t)e * O.Cmax * 2;
-        for (uint32_t idx = j; idx < O.Cmax * 2u; idx += 16u) {
-            const uint32_t r = idx >> 1;
-            int32_t v = 0;
-            if (!blank && r < n_creds) v = (idx & 1u) ? (int32_t)st.cred_port[r & 15u] : (int32_t)st.cred_ext[r & 15u];
-            out[idx] = v;
+        for (uint32_t r = j; r < O.Cmax; r += 16u) {             // (external node index, port) of cache entry r
+            int32_t* out = O.cache_matrix + ((size_t)e * O.Cmax + r) * 2;
+            const bool on = !blank && r < n_creds;
+            const int2 v = make_int2(on ? (int32_t)st.cred_ext[r & 15u] : 0, on ? (int32_t)st.cred_port[r & 15u] : 0);
+            if ((reinterpret_cast<uintptr_t>(out) & 7u) == 0) *reinterpret_cast<int2*>(out) = v;
+            else { out[0] = v.x; out[1] = v.y; }
         }
     }
     if (O.props && NP) {
+        // [Nm][NP] dwords, 0 / 1 per property bit of a discovered node, 0 for the others, all 2 for a blank observation.  Sixteen bytes
+        // per lane and step, the env's 16 lanes side by side (a lane per node ROW was tried: 56-byte lane strides, twice as slow): the
+        // four dwords of a vector belong to node i or i + 1, whose property words are joined into one bit string.
         int32_t* out = O.props + (size_t)e * Nm * NP;
-        uint32_t i = j / NP, p = j - i * NP;
-        const uint32_t di = 16u / NP, dp = 16u - di * NP;
-        for (uint32_t idx = j; idx < Nm * NP; idx += 16u) {
-            int32_t v = blank ? 2 : 0;
-            if (!blank && i < n_disc) v = (int32_t)((st.props[i & 15u] >> p) & 1ull);
-            out[idx] = v;
-            p += dp; i += di;
-            if (p >= NP) { p -= NP; i += 1u; }
+        const uint32_t total = Nm * NP;
+        if (NP >= 4u && (total & 3u) == 0u && (reinterpret_cast<uintptr_t>(out) & 15u) == 0) {
+            const uint32_t di = 64u / NP, dp = 64u - di * NP;    // one step = 16 lanes x 4 dwords
+            uint32_t i = (4u * j) / NP, p = 4u * j - i * NP;
+            const uint64_t row_mask = (1ull << NP) - 1ull;       // NP <= 60
+            for (uint32_t q = j; q < total / 4u; q += 16u) {
+                int4 v = make_int4(2, 2, 2, 2);
+                if (!blank) {
+                    const uint64_t b0 = i < n_disc ? (st.props[i & 15u] & row_mask) : 0ull, b1 = i + 1u < n_disc ? st.props[(i + 1u) & 15u] : 0ull;
+                    const uint32_t nib = (uint32_t)(((b0 | (b1 << NP)) >> p) & 0xFull);       // bits p .. p + 3 <= NP + 2 <= 62
+                    v = make_int4((int32_t)(nib & 1u), (int32_t)((nib >> 1) & 1u), (int32_t)((nib >> 2) & 1u), (int32_t)(nib >> 3));
+                }
+                reinterpret_cast<int4*>(out)[q] = v;
+                p += dp; i += di;
+                if (p >= NP) { p -= NP; i += 1u; }
+            }
+        } else {
+            uint32_t i = j / NP, p = j - i * NP;
+            const uint32_t di = 16u / NP, dp = 16u - di * NP;
+            for (uint32_t idx = j; idx < total; idx += 16u) {
+                int32_t v = blank ? 2 : 0;
+                if (!blank && i < n_disc) v = (int32_t)((st.props[i & 15u] >> p) & 1ull);
+                out[idx] = v;
+                p += dp; i += di;
+                while (p >= NP) { p -= NP; i += 1u; }
+            }
         }
     }
     if (O.priv && j < Nm) O.priv[(size_t)e * Nm + j] = (!blank && j < n_disc) ? (int32_t)st.priv[j] : 0;

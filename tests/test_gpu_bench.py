@@ -42,7 +42,8 @@ def test_bench_line_contract_small_run():
     assert [x["name"] for x in b["configs"]] == ["config3", "config4", "config5"] and all(x["us_per_step"] > 0 for x in b["configs"])
     assert {x["name"] for x in b["observe"]} >= {"headline", "headline_discrete", "headline_mask_logits", "config3"}
     w = b["wrapper"]
-    assert len(w) == 2 and w[0]["last_reward_sum"] == w[1]["last_reward_sum"] and w[1]["us_per_step"] < w[0]["us_per_step"]
+    assert len(w) == 3 and w[0]["last_reward_sum"] == w[1]["last_reward_sum"] == w[2]["last_reward_sum"]
+    assert w[1]["us_per_step"] < w[0]["us_per_step"] and w[2]["us_per_step"] < w[0]["us_per_step"]
     assert "extras_error" not in b
 
 
