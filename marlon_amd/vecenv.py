@@ -66,6 +66,8 @@ class MarlonVecEnv:
             from gymnasium import spaces          # noqa: WPS433 (optional dependency, absent in this image)
         except Exception:
             return None, None
+        if not (hasattr(self.venv, "topo") and hasattr(self.venv, "spec")):     # not one of this package's batched wrappers
+            return None, None
         v, topo = self.venv, self.venv.topo
         N, Cm, K = v.spec.maximum_node_count, v.spec.maximum_total_credentials, v.spec.maximum_discoverable_credentials_per_action
         L, R, P, NP = len(topo.local_vulnerabilities), len(topo.remote_vulnerabilities), len(topo.ports), len(topo.properties)

@@ -83,7 +83,7 @@ def test_vecenv_adapter_follows_dummyvecenv_and_vecmonitor_conventions():
     terminated = [[0, 0, 0], [0, 1, 0], [0, 0, 0], [1, 0, 0]]
     truncated = [[0, 0, 0], [0, 0, 0], [0, 0, 1], [1, 0, 0]]
     env = MarlonVecEnv(ScriptedAttacker(rewards, terminated, truncated))
-    assert env.num_envs == 3 and env.observation_space is None          # gymnasium is not importable in this image
+    assert env.num_envs == 3 and env.observation_space is None          # no gymnasium in this image (and the scripted stand-in has no topology)
     obs = env.reset()
     assert isinstance(obs["connect"], np.ndarray) and obs["connect"].shape == (3, 2, 2)
     masks = np.stack(env.env_method("action_masks"))                    # sb3_contrib get_action_masks
