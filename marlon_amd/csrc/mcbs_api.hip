@@ -675,6 +675,9 @@ static int launch_obs_inner(mcbs_batch* b, const mcbs_obs_buffers* o, hipStream_
         } else if (dwords_ok && reinterpret_cast<uintptr_t>(o->mask_connect) % 4 == 0) O.fuse_connect = 2;                  // dwords, any RL
     }
     O.nt_connect = (O.fuse_connect == 1 && M % 128 == 0 && reinterpret_cast<uintptr_t>(o->mask_connect) % 128 == 0) ? 1u : 0u;
+    auto fdh = [](size_t d) { return fast_div_host(d ? (uint32_t)d : 1u); };
+    O.dNP = fdh(b->C.n_props); O.dL = fdh(b->C.L); O.dR = fdh(b->C.R); O.dNm = fdh(O.Nmax); O.dRL = fdh(RL); O.dC = fdh(O.Cmax);
+    O.dPC = fdh(O.conn_pc); O.dCPR = fdh(RL >> 4);
     O.fuse_discrete = dwords_ok && o->mask_discrete && ML % 4 == 0 && MR % 4 == 0 && b->C.L > 0 && b->C.R > 0 &&
                       reinterpret_cast<uintptr_t>(o->mask_discrete) % 4 == 0;
     const uint32_t obs_shm = 4u * obs_stage_bytes(b->S.N, b->topo->H()->n_triples);

@@ -189,6 +189,12 @@ struct StepIO {
 #endif
 };
 
+struct FastDiv { uint32_t mul, sh1, sh2; };   // n / d for 32-bit n (Granlund-Montgomery round-up form), set up on the host
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv d) {
+    const uint32_t t = __umulhi(n, d.mul);
+    return (t + ((n - t) >> d.sh1)) >> d.sh2;
+}
+
 struct ObsIO {
     int32_t* scalars; int32_t* leaked; int32_t* cache_matrix; int32_t* props; int32_t* priv;
     int8_t* mask_local; int8_t* mask_remote; int8_t* mask_connect; int8_t* mask_discrete;
@@ -203,6 +209,9 @@ struct ObsIO {
     uint32_t conn_pc;      // fuse_connect == 3: chunks per pattern period, lcm(P*C, 16) / 16
     uint32_t nt_connect;   // 1: the fused connect stream uses non-temporal stores (every env's mask is whole 128-byte lines)
     uint32_t fuse_discrete; // 1: mask_discrete (connect | local | remote per env, 4-byte granularity) written by obs_small_kernel
+    // divisors of the observation's index arithmetic (a generic 32-bit division costs ~25 instructions per lane, and the per-env
+    // routine had a score of them): properties per node, local / remote ids, Nmax, row length P*C, Cmax, pattern period, chunks per row
+    FastDiv dNP, dL, dR, dNm, dRL, dC, dPC, dCPR;
 };
 
 // Local-vulnerability mask of node n as the action mask sees it (env.py:653-659): static, except under ExternalRandomEvents where

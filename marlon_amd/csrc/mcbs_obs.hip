@@ -176,8 +176,8 @@ __device__ __forceinline__ void obs_env(const DevState& S, const Topo& T, const 
         }
         if (O.props && NP) {
             int32_t* out = O.props + (size_t)e * Nm * NP;
-            uint32_t i = lane / NP, p = lane - i * NP;             // (node, property) of flat index `lane`, then advanced by 64
-            const uint32_t di = 64u / NP, dp = 64u - di * NP;
+            uint32_t i = fdiv(lane, O.dNP), p = lane - i * NP;      // (node, property) of flat index `lane`, then advanced by 64
+            const uint32_t di = fdiv(64u, O.dNP), dp = 64u - di * NP;
             for (uint32_t idx = lane; idx < Nm * NP; idx += 64u) {
                 int32_t v = blank ? 2 : 0;
                 if (!blank && i < n_disc) v = (int32_t)((st.props[i] >> p) & 1ull);
@@ -194,7 +194,7 @@ __device__ __forceinline__ void obs_env(const DevState& S, const Topo& T, const 
     if (O.mask_local) {
         int8_t* out = O.mask_local + (size_t)e * Nm * L;
         for (uint32_t idx = lane; idx < Nm * L; idx += 64u) {
-            const uint32_t i = idx / L, l = idx - i * L;
+            const uint32_t i = fdiv(idx, O.dL), l = idx - i * L;
             int8_t v = 0;
             if (!blank && i < n_disc && ((own_ext[i >> 6] >> (i & 63u)) & 1ull)) v = (int8_t)((st.lmask[i] >> l) & 1u);
             out[idx] = v;
@@ -208,7 +208,7 @@ __device__ __forceinline__ void obs_env(const DevState& S, const Topo& T, const 
 #pragma unroll
     for (uint32_t k = 0; k < 4; ++k) {
         if (k * 64u < rows) {                 // wave-uniform
-            const uint32_t q = k * 64u + lane, s = q / Nm, t = q - s * Nm;
+            const uint32_t q = k * 64u + lane, s = fdiv(q, O.dNm), t = q - s * Nm;
             const bool v = !blank && q < rows && ((own_ext[(s >> 6) & 3u] >> (s & 63u)) & 1ull) && t < n_disc;
             on[k] = __ballot(v);
             st.onb[q] = v ? 1 : 0;
@@ -220,16 +220,52 @@ __device__ __forceinline__ void obs_env(const DevState& S, const Topo& T, const 
         const uint64_t w = k == 0 ? on[0] : (k == 1 ? on[1] : (k == 2 ? on[2] : on[3]));
         return (w >> (q & 63u)) & 1ull;
     };
-    if (O.fuse_remote) {                      // remote[s][t][r] = on(s, t): 4 bytes per lane and iteration (MR is a multiple of 4)
-        const uint32_t R = C.R, MR = rows * R;
-        uint32_t* out = reinterpret_cast<uint32_t*>(O.mask_remote + (size_t)e * MR);
-        for (uint32_t i0 = lane * 4u; i0 < MR; i0 += 256u) {
-            uint32_t v = 0;
+    // DEAD SPANS.  What one store instruction of the wavefront covers (a span: 64 lanes x 4 or 16 bytes) touches a handful of
+    // consecutive rows, and most rows are off for most of an episode (a few owned sources x the discovered targets): when no row of the
+    // span is on — a scalar test of the ballot words — the span is zeros and none of the per-lane pattern work is done.  The SQ
+    // counters had these kernels bound by instruction issue, not by HBM (1 200–1 800 VALU instructions per 12–15 KB wavefront;
+    // profiles/round2_notes.md section 3c).
+    auto any_on = [&](uint32_t qlo, uint32_t qhi) -> bool {       // uniform arguments: is a row in qlo .. qhi (inclusive) on?
+        bool any = false;
 #pragma unroll
-            for (uint32_t b = 0; b < 4u; ++b) v |= (uint32_t)row_on((i0 + b) / R) << (8u * b);
-            out[i0 >> 2] = v;
+        for (uint32_t k = 0; k < 4u; ++k) {
+            const uint32_t lo = k * 64u;
+            if (qhi >= lo && qlo <= lo + 63u) {
+                const uint32_t a = qlo > lo ? qlo - lo : 0u, b = qhi < lo + 63u ? qhi - lo : 63u;
+                const uint64_t m = (b == 63u ? ~0ull : ((1ull << (b + 1u)) - 1ull)) & ~((1ull << a) - 1ull);
+                any |= (on[k] & m) != 0ull;
+            }
         }
-    }
+        return any;
+    };
+    // remote[s][t][r] = on(s, t): 4 bytes per lane and iteration (MR is a multiple of 4), (row, offset in row) advanced incrementally
+    auto stream_remote_dwords = [&](uint32_t* out) {
+        const uint32_t R = C.R, MR = rows * R;
+        if (R >= 4u) {
+            const uint32_t dq = fdiv(256u, O.dR), dr = 256u - dq * R, span_rows = fdiv(256u + R - 2u, O.dR) + 1u;
+            uint32_t q = fdiv(lane * 4u, O.dR), r = lane * 4u - q * R;
+            for (uint32_t i0 = lane * 4u; i0 < MR; i0 += 256u) {
+                const uint32_t qf = __builtin_amdgcn_readfirstlane(q), ql = qf + span_rows < 259u ? qf + span_rows : 259u;
+                uint32_t v = 0;
+                if (any_on(qf, ql)) {
+                    const uint32_t nb = R - r;                                // bytes of this dword inside row q (>= 4: all)
+                    const uint32_t mq = nb >= 4u ? 0x01010101u : ((1u << (8u * nb)) - 1u) & 0x01010101u;
+                    v = (row_on(q) ? mq : 0u) | (row_on(q + 1u) ? (0x01010101u & ~mq) : 0u);
+                }
+                out[i0 >> 2] = v;
+                r += dr; q += dq;
+                if (r >= R) { r -= R; q += 1u; }
+            }
+        } else {
+            for (uint32_t i0 = lane * 4u; i0 < MR; i0 += 256u) {
+                uint32_t v = 0;
+#pragma unroll
+                for (uint32_t b = 0; b < 4u; ++b) v |= (uint32_t)row_on(fdiv(i0 + b, O.dR)) << (8u * b);
+                out[i0 >> 2] = v;
+            }
+        }
+    };
+    if (O.fuse_remote) stream_remote_dwords(reinterpret_cast<uint32_t*>(O.mask_remote + (size_t)e * rows * C.R));
     // General form of the connect region, any row length RL (ToyCtf: 70 bytes), as dwords: the bytes of one "on" row sit in LDS
     // followed by its first four bytes again, so the dword at row offset r is two aligned LDS words shifted by r & 3; the bytes
     // that spill into the next row take that row's on/off.  (row, offset) advance incrementally by 256 bytes per iteration.
@@ -240,7 +276,7 @@ __device__ __forceinline__ void obs_env(const DevState& S, const Topo& T, const 
         for (uint32_t wd = lane; wd < nw; wd += 64u) {
             uint32_t r = wd * 4u, w = 0;
             if (r >= RL) r -= RL;
-            uint32_t c = r % Cc;
+            uint32_t c = r - fdiv(r, O.dC) * Cc;
 #pragma unroll
             for (uint32_t i = 0; i < 4u; ++i) {
                 w |= (uint32_t)(c < n_creds) << (8u * i);
@@ -252,14 +288,19 @@ __device__ __forceinline__ void obs_env(const DevState& S, const Topo& T, const 
         }
         __builtin_amdgcn_wave_barrier();
         __threadfence_block();
-        const uint32_t total = (rows * RL) >> 2, dq = 256u / RL, dr = 256u - dq * RL;
-        uint32_t b0 = lane * 4u, q = b0 / RL, r = b0 - q * RL;
+        const uint32_t total = (rows * RL) >> 2, dq = fdiv(256u, O.dRL), dr = 256u - dq * RL, span_rows = fdiv(256u + RL - 2u, O.dRL) + 1u;
+        uint32_t b0 = lane * 4u, q = fdiv(b0, O.dRL), r = b0 - q * RL;
         for (uint32_t k = lane; k < total; k += 64u) {
-            const uint32_t lo = pat[r >> 2], hi = pat[(r >> 2) + 1u];
-            const uint32_t w = __builtin_amdgcn_alignbyte(hi, lo, r & 3u);
-            const uint32_t nb = RL - r;                                   // bytes of this dword inside row q (>= 4: all)
-            const uint32_t mq = nb >= 4u ? 0xFFFFFFFFu : ((1u << (8u * nb)) - 1u);
-            out[k] = w & ((st.onb[q] ? mq : 0u) | (st.onb[q + 1u] ? ~mq : 0u));
+            const uint32_t qf = __builtin_amdgcn_readfirstlane(q), ql = qf + span_rows < 259u ? qf + span_rows : 259u;
+            uint32_t v = 0;
+            if (any_on(qf, ql)) {                                         // (uniform)
+                const uint32_t lo = pat[r >> 2], hi = pat[(r >> 2) + 1u];
+                const uint32_t w = __builtin_amdgcn_alignbyte(hi, lo, r & 3u);
+                const uint32_t nb = RL - r;                               // bytes of this dword inside row q (>= 4: all)
+                const uint32_t mq = nb >= 4u ? 0xFFFFFFFFu : ((1u << (8u * nb)) - 1u);
+                v = w & ((st.onb[q] ? mq : 0u) | (st.onb[q + 1u] ? ~mq : 0u));
+            }
+            out[k] = v;
             r += dr; q += dq;
             if (r >= RL) { r -= RL; q += 1u; }
         }
@@ -272,7 +313,7 @@ __device__ __forceinline__ void obs_env(const DevState& S, const Topo& T, const 
         const uint32_t Cc = O.Cmax, RL = C.P * Cc, PC = O.conn_pc;
         __builtin_amdgcn_wave_barrier();               // (an earlier pattern may still be in use by other lanes)
         if (lane < PC) {
-            uint32_t r = (lane * 16u) % RL, c = r % Cc, w[4] = {0, 0, 0, 0};
+            uint32_t r = lane * 16u - fdiv(lane * 16u, O.dRL) * RL, c = r - fdiv(r, O.dC) * Cc, w[4] = {0, 0, 0, 0};
 #pragma unroll
             for (uint32_t i = 0; i < 16u; ++i) {
                 w[i >> 2] |= (uint32_t)(c < n_creds) << (8u * (i & 3u));
@@ -285,20 +326,26 @@ __device__ __forceinline__ void obs_env(const DevState& S, const Topo& T, const 
         __builtin_amdgcn_wave_barrier();
         __threadfence_block();
         uint4* out = reinterpret_cast<uint4*>(O.mask_connect + (size_t)e * rows * RL);
-        const uint32_t total = (rows * RL) >> 4, dq = 1024u / RL, dr = 1024u - dq * RL, dj = 64u % PC;
-        uint32_t q = (lane * 16u) / RL, r0 = lane * 16u - q * RL, pj = lane % PC;
+        const uint32_t total = (rows * RL) >> 4, dq = fdiv(1024u, O.dRL), dr = 1024u - dq * RL, dj = 64u - fdiv(64u, O.dPC) * PC,
+                       span_rows = fdiv(1024u + RL - 2u, O.dRL) + 1u;
+        uint32_t q = fdiv(lane * 16u, O.dRL), r0 = lane * 16u - q * RL, pj = lane - fdiv(lane, O.dPC) * PC;
         for (uint32_t c = lane; c < total; c += 64u) {
-            const uint4 p = st.pat[pj];
-            const uint32_t b = RL - r0;                                  // bytes of this chunk inside row q (>= 16: all)
-            const uint32_t a0 = st.onb[q] ? 0xFFFFFFFFu : 0u, a1 = st.onb[q + 1u] ? 0xFFFFFFFFu : 0u;
-            uint32_t sel[4];
+            const uint32_t qf = __builtin_amdgcn_readfirstlane(q), ql = qf + span_rows < 259u ? qf + span_rows : 259u;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (any_on(qf, ql)) {                                        // (uniform)
+                const uint4 p = st.pat[pj];
+                const uint32_t b = RL - r0;                              // bytes of this chunk inside row q (>= 16: all)
+                const uint32_t a0 = st.onb[q] ? 0xFFFFFFFFu : 0u, a1 = st.onb[q + 1u] ? 0xFFFFFFFFu : 0u;
+                uint32_t sel[4];
 #pragma unroll
-            for (uint32_t d4 = 0; d4 < 4u; ++d4) {
-                const uint32_t lo = 4u * d4;                             // dword d4 holds bytes lo .. lo + 3 of the chunk
-                const uint32_t m = b >= lo + 4u ? 0xFFFFFFFFu : (b <= lo ? 0u : ((1u << (8u * (b - lo))) - 1u));
-                sel[d4] = (a0 & m) | (a1 & ~m);
+                for (uint32_t d4 = 0; d4 < 4u; ++d4) {
+                    const uint32_t lo = 4u * d4;                         // dword d4 holds bytes lo .. lo + 3 of the chunk
+                    const uint32_t m = b >= lo + 4u ? 0xFFFFFFFFu : (b <= lo ? 0u : ((1u << (8u * (b - lo))) - 1u));
+                    sel[d4] = (a0 & m) | (a1 & ~m);
+                }
+                v = make_uint4(p.x & sel[0], p.y & sel[1], p.z & sel[2], p.w & sel[3]);
             }
-            out[c] = make_uint4(p.x & sel[0], p.y & sel[1], p.z & sel[2], p.w & sel[3]);
+            out[c] = v;
             r0 += dr; q += dq; pj += dj;
             if (r0 >= RL) { r0 -= RL; q += 1u; }
             if (pj >= PC) pj -= PC;
@@ -312,7 +359,7 @@ __device__ __forceinline__ void obs_env(const DevState& S, const Topo& T, const 
         // kilobyte per store instruction, with (row, chunk-in-row) advanced incrementally instead of divided out per chunk.
         const uint32_t Cc = O.Cmax, RL = C.P * Cc, cpr = RL >> 4;
         if (lane < cpr) {
-            uint32_t c = (lane * 16u) % Cc, w[4] = {0, 0, 0, 0};
+            uint32_t c = lane * 16u - fdiv(lane * 16u, O.dC) * Cc, w[4] = {0, 0, 0, 0};
 #pragma unroll
             for (uint32_t i = 0; i < 16u; ++i) {
                 w[i >> 2] |= (uint32_t)(c < n_creds) << (8u * (i & 3u));
@@ -323,11 +370,15 @@ __device__ __forceinline__ void obs_env(const DevState& S, const Topo& T, const 
         __builtin_amdgcn_wave_barrier();
         __threadfence_block();
         uint4* out = reinterpret_cast<uint4*>(O.mask_connect + (size_t)e * rows * RL);
-        const uint32_t total = rows * cpr, dq = 64u / cpr, dj = 64u - dq * cpr;
-        uint32_t q = lane / cpr, j = lane - q * cpr;
+        const uint32_t total = rows * cpr, dq = fdiv(64u, O.dCPR), dj = 64u - dq * cpr, span_rows = dq + 1u;
+        uint32_t q = fdiv(lane, O.dCPR), j = lane - q * cpr;
         for (uint32_t c = lane; c < total; c += 64u) {
-            const uint4 p = st.pat[j];
-            const uint4 v = row_on(q) ? p : make_uint4(0, 0, 0, 0);
+            const uint32_t qf = __builtin_amdgcn_readfirstlane(q), ql = qf + span_rows < 259u ? qf + span_rows : 259u;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (any_on(qf, ql)) {                                               // (uniform)
+                const uint4 p = st.pat[j];
+                v = row_on(q) ? p : make_uint4(0, 0, 0, 0);
+            }
             if (O.nt_connect) stream_store16(out + c, v); else out[c] = v;      // (uniform)
             j += dj; q += dq;
             if (j >= cpr) { j -= cpr; q += 1u; }
@@ -343,13 +394,13 @@ __device__ __forceinline__ void obs_env(const DevState& S, const Topo& T, const 
         const uint32_t cpr = RL >> 4;
         // value of byte b of the env's flat mask (connect | local | remote), for the few bytes not covered by whole 16-byte chunks
         auto byte_at = [&](uint32_t b) -> uint32_t {
-            if (b < M) { const uint32_t q = b / RL, r = b - q * RL; return (uint32_t)(row_on(q) && (r % O.Cmax) < n_creds); }
+            if (b < M) { const uint32_t q = fdiv(b, O.dRL), r = b - q * RL; return (uint32_t)(row_on(q) && (r - fdiv(r, O.dC) * O.Cmax) < n_creds); }
             b -= M;
             if (b < ML) {
-                const uint32_t i = b / L, l = b - i * L;
+                const uint32_t i = fdiv(b, O.dL), l = b - i * L;
                 return (uint32_t)(!blank && i < n_disc && ((own_ext[(i >> 6) & 3u] >> (i & 63u)) & 1ull) && ((st.lmask[i & 255u] >> l) & 1u));
             }
-            return (uint32_t)row_on((b - ML) / R);
+            return (uint32_t)row_on(fdiv(b - ML, O.dR));
         };
         if ((RL & 15u) == 0u && cpr <= 64u && M >= 64u) {
             // Row length a multiple of 16 (Chain-10: 96): env bases are only 4-byte aligned (the flat length, 14 172, is not a multiple of
@@ -361,7 +412,7 @@ __device__ __forceinline__ void obs_env(const DevState& S, const Topo& T, const 
             if (lane < cpr) {
                 uint32_t r = h + lane * 16u, w[4] = {0, 0, 0, 0};
                 if (r >= RL) r -= RL;
-                uint32_t c = r % Cc;
+                uint32_t c = r - fdiv(r, O.dC) * Cc;
 #pragma unroll
                 for (uint32_t i = 0; i < 16u; ++i) {
                     w[i >> 2] |= (uint32_t)(c < n_creds) << (8u * (i & 3u));
@@ -379,23 +430,28 @@ __device__ __forceinline__ void obs_env(const DevState& S, const Topo& T, const 
                 for (uint32_t b = 0; b < 4u; ++b) v |= byte_at(lane * 4u + b) << (8u * b);
                 reinterpret_cast<uint32_t*>(base)[lane] = v;
             }
-            const uint32_t nchunks = (M - h) >> 4, dq = 64u / cpr, dj = 64u - dq * cpr;
+            const uint32_t nchunks = (M - h) >> 4, dq = fdiv(64u, O.dCPR), dj = 64u - dq * cpr;
             uint4* out16 = reinterpret_cast<uint4*>(base + h);
 
-            uint32_t q = (h + lane * 16u) / RL, j = ((h + lane * 16u) - q * RL - h) >> 4;
+            uint32_t q = fdiv(h + lane * 16u, O.dRL), j = ((h + lane * 16u) - q * RL - h) >> 4;
             // bytes [0, 16 - h) of a straddling chunk belong to row q, the rest to row q + 1
             const uint32_t nb = 16u - h;
             uint32_t keep[4];
 #pragma unroll
             for (uint32_t k = 0; k < 4u; ++k) keep[k] = nb >= 4u * (k + 1u) ? 0xFFFFFFFFu : (nb <= 4u * k ? 0u : ((1u << (8u * (nb - 4u * k))) - 1u));
+            const uint32_t span_rows = dq + 2u;
             for (uint32_t c = lane; c < nchunks; c += 64u) {
-                const uint4 p = st.pat[j];
-                const uint32_t a = row_on(q) ? 0xFFFFFFFFu : 0u;
-                uint4 v = make_uint4(p.x & a, p.y & a, p.z & a, p.w & a);
-                if (h && j == cpr - 1u) {
-                    const uint32_t nx = row_on(q + 1u) ? 0xFFFFFFFFu : 0u;
-                    v = make_uint4(p.x & ((a & keep[0]) | (nx & ~keep[0])), p.y & ((a & keep[1]) | (nx & ~keep[1])),
-                                   p.z & ((a & keep[2]) | (nx & ~keep[2])), p.w & ((a & keep[3]) | (nx & ~keep[3])));
+                const uint32_t qf = __builtin_amdgcn_readfirstlane(q), ql = qf + span_rows < 259u ? qf + span_rows : 259u;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (any_on(qf, ql)) {                                    // (uniform)
+                    const uint4 p = st.pat[j];
+                    const uint32_t a = row_on(q) ? 0xFFFFFFFFu : 0u;
+                    v = make_uint4(p.x & a, p.y & a, p.z & a, p.w & a);
+                    if (h && j == cpr - 1u) {
+                        const uint32_t nx = row_on(q + 1u) ? 0xFFFFFFFFu : 0u;
+                        v = make_uint4(p.x & ((a & keep[0]) | (nx & ~keep[0])), p.y & ((a & keep[1]) | (nx & ~keep[1])),
+                                       p.z & ((a & keep[2]) | (nx & ~keep[2])), p.w & ((a & keep[3]) | (nx & ~keep[3])));
+                    }
                 }
                 out16[c] = v;
                 j += dj; q += dq;
@@ -419,12 +475,7 @@ __device__ __forceinline__ void obs_env(const DevState& S, const Topo& T, const 
             out[i0 >> 2] = v;
         }
         out += ML >> 2;
-        for (uint32_t i0 = lane * 4u; i0 < MR; i0 += 256u) {
-            uint32_t v = 0;
-#pragma unroll
-            for (uint32_t b = 0; b < 4u; ++b) v |= (uint32_t)row_on((i0 + b) / R) << (8u * b);
-            out[i0 >> 2] = v;
-        }
+        stream_remote_dwords(out);
         }
     }
 }
@@ -530,8 +581,8 @@ __global__ __launch_bounds__(256) void obs_tiny_kernel(DevState S, Topo T, const
         int32_t* out = O.props + (size_t)e * Nm * NP;
         const uint32_t total = Nm * NP;
         if (NP >= 4u && (total & 3u) == 0u && (reinterpret_cast<uintptr_t>(out) & 15u) == 0) {
-            const uint32_t di = 64u / NP, dp = 64u - di * NP;    // one step = 16 lanes x 4 dwords
-            uint32_t i = (4u * j) / NP, p = 4u * j - i * NP;
+            const uint32_t di = fdiv(64u, O.dNP), dp = 64u - di * NP;    // one step = 16 lanes x 4 dwords
+            uint32_t i = fdiv(4u * j, O.dNP), p = 4u * j - i * NP;
             const uint64_t row_mask = (1ull << NP) - 1ull;       // NP <= 60
             for (uint32_t q = j; q < total / 4u; q += 16u) {
                 int4 v = make_int4(2, 2, 2, 2);
@@ -545,8 +596,8 @@ __global__ __launch_bounds__(256) void obs_tiny_kernel(DevState S, Topo T, const
                 if (p >= NP) { p -= NP; i += 1u; }
             }
         } else {
-            uint32_t i = j / NP, p = j - i * NP;
-            const uint32_t di = 16u / NP, dp = 16u - di * NP;
+            uint32_t i = fdiv(j, O.dNP), p = j - i * NP;
+            const uint32_t di = fdiv(16u, O.dNP), dp = 16u - di * NP;
             for (uint32_t idx = j; idx < total; idx += 16u) {
                 int32_t v = blank ? 2 : 0;
                 if (!blank && i < n_disc) v = (int32_t)((st.props[i & 15u] >> p) & 1ull);
@@ -650,11 +701,6 @@ __global__ __launch_bounds__(256) void mask_kernel(DevState S, Topo T, const Ste
 // pattern depends only on (byte index mod C) across the whole env, and rows only switch it on or off.
 // remote[s][t][r] = own(s) && t < n_disc is, per source row of RL = N*R bytes, "n_disc*R ones then zeros" (C = RL).
 // A thread therefore builds its 16 bytes from two byte-range masks instead of walking them one by one.
-struct FastDiv { uint32_t mul, sh1, sh2; };   // n / d for 32-bit n (Granlund-Montgomery round-up form), set up on the host
-__device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv d) {
-    const uint32_t t = __umulhi(n, d.mul);
-    return (t + ((n - t) >> d.sh1)) >> d.sh2;
-}
 __device__ __forceinline__ void ones_upto(uint32_t k, uint64_t& lo, uint64_t& hi) {   // bytes [0,k) = 0xFF, k in 0..16
     lo = k >= 8u ? ~0ull : (k ? (~0ull >> (64u - 8u * k)) : 0ull);
     hi = k <= 8u ? 0ull : (k >= 16u ? ~0ull : (~0ull >> (64u - 8u * (k - 8u))));
