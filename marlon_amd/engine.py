@@ -384,9 +384,10 @@ class BatchEngine:
         mk = lambda n: t.zeros((self.E, n), dtype=t.int8, device=self.device)
         return dict(infected_nodes=mk(N), incoming_firewall_status=mk(6 * N), outgoing_firewall_status=mk(6 * N), services_status=mk(S))
 
-    def defender_step(self, actions12, obs: Optional[dict] = None):
+    def defender_step(self, actions12, obs: Optional[dict] = None, out=None):
         """DefenderEnvWrapper's validity check + LearningDefender.executeAction for every env.
-        -> (valid u8 [E], availability f64 [E], evicted u8 [E]) device tensors."""
+        -> (valid u8 [E], availability f64 [E], evicted u8 [E]) device tensors (`out`: that triple, caller-owned; default: the engine's own
+        buffers, overwritten by the next call)."""
         t = self.torch
         a = actions12 if isinstance(actions12, t.Tensor) else t.as_tensor(np.asarray(actions12))
         a = a.to(device=self.device, dtype=t.int64).contiguous()
@@ -395,7 +396,7 @@ class BatchEngine:
         if not hasattr(self, "_def_out"):
             self._def_out = (t.zeros(self.E, dtype=t.uint8, device=self.device), t.zeros(self.E, dtype=t.float64, device=self.device),
                              t.zeros(self.E, dtype=t.uint8, device=self.device))
-        v, av, ev = self._def_out
+        v, av, ev = self._def_out if out is None else out
         o = DefenderObs(**{k: x.data_ptr() for k, x in obs.items()}) if obs is not None else None
         _check(self.lib, self.lib.mcbs_defender_step(self._h, a.data_ptr(), v.data_ptr(), av.data_ptr(), ev.data_ptr(),
                                                      C.byref(o) if o is not None else None, self._stream()), "mcbs_defender_step")

@@ -265,7 +265,7 @@ class DefenderVecEnv:
         self.prev_availability = t.ones(E, dtype=t.float64, device=dev)
         self.valid_action_count = t.zeros(E, dtype=t.int64, device=dev)
         self.invalid_action_count = t.zeros(E, dtype=t.int64, device=dev)
-        self._wb = None
+        self._wb = self._evicted = None
         # use_graph: the defender's turn (validity + executeAction + observation, reward shaping) captured once and replayed as one
         # hipGraph; outputs are then the wrapper's own buffers (overwritten by the next step)
         self.use_graph = bool(use_graph)
@@ -290,9 +290,9 @@ class DefenderVecEnv:
         self.prev_availability.copy_(t.where(keep, self.prev_availability, avail))    # in place: the fused shaping launch holds its address
         return self._obs
 
-    def _step_device(self, actions):
+    def _step_device(self, actions, out=None):
         t = self.torch
-        valid, avail, evicted = self.engine.defender_step(actions, self._obs)
+        valid, avail, evicted = self.engine.defender_step(actions, self._obs, out=out)
         if self._wb is None:        # reward shaping (defend_wrapper.py:228-282) for the whole batch in one launch
             from ._abi import DefenderWrapperBuffers, DefenderWrapperCfg
             E, dev = self.num_envs, self.engine.device
@@ -331,8 +331,20 @@ class DefenderVecEnv:
             info = {"valid_action": valid.view(t.bool), "network_availability": avail, "sla_breached": self._out["breached"].view(t.bool),
                     "defender_won": self._out["won"].view(t.bool)}
             return self._obs, self._out["reward"], self._out["terminated"], self._out["truncated"], info
-        valid, avail = self._step_device(actions)
-        reward, terminated, truncated = self._out["reward"].clone(), self._out["terminated"].clone(), self._out["truncated"].clone()
-        info = {"valid_action": valid.view(t.bool).clone(), "network_availability": avail.clone(), "sla_breached": self._out["breached"].view(t.bool).clone(),
-                "defender_won": self._out["won"].view(t.bool).clone()}
-        return self._obs, reward, terminated, truncated, info
+        # eager: this turn's outputs are tensors of their own, written by the two launches directly (no clones of persistent buffers)
+        E, dev = self.num_envs, self.engine.device
+        if self._evicted is None:
+            self._evicted = t.zeros(E, dtype=t.uint8, device=dev)
+        fresh = dict(valid=t.empty(E, dtype=t.uint8, device=dev), availability=t.empty(E, dtype=t.float64, device=dev),
+                     reward=t.empty(E, dtype=t.float64, device=dev), terminated=t.empty(E, dtype=t.uint8, device=dev),
+                     truncated=t.empty(E, dtype=t.uint8, device=dev), breached=t.empty(E, dtype=t.uint8, device=dev), won=t.empty(E, dtype=t.uint8, device=dev))
+        first = self._wb is None                # the first turn builds the argument block (on buffers of its own for the shaping outputs)
+        if not first:
+            for k, x in fresh.items():
+                setattr(self._wb, k, x.data_ptr())
+            self._out = {k: fresh[k] for k in ("reward", "terminated", "truncated", "breached", "won")}
+        valid, avail = self._step_device(actions, out=(fresh["valid"], fresh["availability"], self._evicted))
+        out = {k: v.clone() for k, v in self._out.items()} if first else self._out
+        info = {"valid_action": valid.view(t.bool), "network_availability": avail, "sla_breached": out["breached"].view(t.bool),
+                "defender_won": out["won"].view(t.bool)}
+        return self._obs, out["reward"], out["terminated"], out["truncated"], info
