@@ -823,8 +823,8 @@ extern "C" int mcbs_copy_rows_masked(mcbs_batch* b, const mcbs_row_copies* copie
     return launch_ok("copy rows");
 }
 
-extern "C" int mcbs_attacker_wrapper_finish(mcbs_batch* b, const mcbs_wrapper_buffers* w, float modifier, int32_t max_timesteps, int32_t auto_reset,
-                                            const mcbs_row_copies* keep, const mcbs_row_copies* fresh, void* stream) {
+static int finish_args(mcbs_batch* b, const mcbs_wrapper_buffers* w, float modifier, int32_t max_timesteps, int32_t auto_reset,
+                       const mcbs_row_copies* keep, const mcbs_row_copies* fresh, WrapperFinishArgs* A) {
     if (!b || !w) return fail(MCBS_EINVAL, "null argument");
     const void* const* p = reinterpret_cast<const void* const*>(w);
     for (size_t i = 0; i + 2 < sizeof(*w) / sizeof(void*); ++i)          // n_done and executed (the last two members) may be NULL
@@ -837,10 +837,46 @@ extern "C" int mcbs_attacker_wrapper_finish(mcbs_batch* b, const mcbs_wrapper_bu
     }
     if (auto_reset && !b->reset_digest_ok)
         return fail(MCBS_ESTATE, "no reset observation yet: reset the whole batch (mcbs_reset, NULL mask) and observe it once before the first call");
+    A->w = *w; A->modifier = modifier; A->max_timesteps = max_timesteps; A->auto_reset = auto_reset; A->pad = 0;
+    A->keep = *rc[0]; A->fresh = *rc[1]; A->digest = b->digest; A->reset_digest = b->reset_digest;
+    return MCBS_OK;
+}
+
+extern "C" int mcbs_attacker_wrapper_finish(mcbs_batch* b, const mcbs_wrapper_buffers* w, float modifier, int32_t max_timesteps, int32_t auto_reset,
+                                            const mcbs_row_copies* keep, const mcbs_row_copies* fresh, void* stream) {
+    WrapperFinishArgs A;
+    const int rc = finish_args(b, w, modifier, max_timesteps, auto_reset, keep, fresh, &A);
+    if (rc) return rc;
     b->all_fresh = false;
-    hipLaunchKernelGGL(wrapper_finish_kernel, dim3((b->S.E + 255) / 256), dim3(256), 0, (hipStream_t)stream, b->S, b->T, *w, modifier, max_timesteps,
-                       (int)auto_reset, *rc[0], *rc[1], b->digest, b->reset_digest);
+    hipLaunchKernelGGL(wrapper_finish_kernel, dim3((b->S.E + 255) / 256), dim3(256), 0, (hipStream_t)stream, b->S, b->T, A);
     return launch_ok("wrapper finish");
+}
+
+template <int WT, int DEF>
+static void launch_step2_finish_v(mcbs_batch* b, const StepIO& io, const WrapperFinishArgs& A, hipStream_t st) {
+    const uint32_t shm = b->S.wide ? 64u * b->S.TW * 8u : 0u;
+    hipLaunchKernelGGL((step2_finish_kernel<WT, DEF>), dim3((b->S.E + 63u) / 64u), dim3(64), shm, st, b->S, b->T, b->C_dev, io, A);
+}
+template <int WT>
+static void launch_step2_finish_nw(mcbs_batch* b, const StepIO& io, const WrapperFinishArgs& A, hipStream_t st) {
+    if (b->cfg.defender_kind == MCBS_DEFENDER_SCAN_AND_REIMAGE) launch_step2_finish_v<WT, MCBS_DEFENDER_SCAN_AND_REIMAGE>(b, io, A, st);
+    else if (b->cfg.defender_kind == MCBS_DEFENDER_RANDOM_EVENTS) launch_step2_finish_v<WT, MCBS_DEFENDER_RANDOM_EVENTS>(b, io, A, st);
+    else if (b->cfg.defender_kind == MCBS_DEFENDER_EXTERNAL) launch_step2_finish_v<WT, MCBS_DEFENDER_EXTERNAL>(b, io, A, st);
+    else launch_step2_finish_v<WT, MCBS_DEFENDER_NONE>(b, io, A, st);
+}
+
+template <int WT, int DEF>
+static void launch_decode_step1_v(mcbs_batch* b, const StepIO& io, const int64_t* md, const int64_t* discrete, uint8_t* invalid, hipStream_t st) {
+    const uint32_t shm = b->S.wide ? 64u * b->S.TW * 8u : 0u;
+    hipLaunchKernelGGL((decode_step1_kernel<WT, DEF>), dim3((b->S.E + 63u) / 64u), dim3(64), shm, st, b->S, b->T, b->C_dev, io,
+                       b->cfg.maximum_node_count, b->cfg.maximum_total_credentials, md, discrete, invalid);
+}
+template <int WT>
+static void launch_decode_step1_nw(mcbs_batch* b, const StepIO& io, const int64_t* md, const int64_t* discrete, uint8_t* invalid, hipStream_t st) {
+    if (b->cfg.defender_kind == MCBS_DEFENDER_SCAN_AND_REIMAGE) launch_decode_step1_v<WT, MCBS_DEFENDER_SCAN_AND_REIMAGE>(b, io, md, discrete, invalid, st);
+    else if (b->cfg.defender_kind == MCBS_DEFENDER_RANDOM_EVENTS) launch_decode_step1_v<WT, MCBS_DEFENDER_RANDOM_EVENTS>(b, io, md, discrete, invalid, st);
+    else if (b->cfg.defender_kind == MCBS_DEFENDER_EXTERNAL) launch_decode_step1_v<WT, MCBS_DEFENDER_EXTERNAL>(b, io, md, discrete, invalid, st);
+    else launch_decode_step1_v<WT, MCBS_DEFENDER_NONE>(b, io, md, discrete, invalid, st);
 }
 
 extern "C" int mcbs_attacker_wrapper_step(mcbs_batch* b, const int64_t* multidiscrete, const int64_t* discrete, int32_t* decoded,
@@ -848,10 +884,37 @@ extern "C" int mcbs_attacker_wrapper_step(mcbs_batch* b, const int64_t* multidis
                                           int32_t max_timesteps, int32_t auto_reset, const mcbs_row_copies* keep, const mcbs_row_copies* fresh,
                                           void* stream) {
     if (!b || !w || !decoded || !obs) return fail(MCBS_EINVAL, "null argument");
-    int rc = mcbs_decode_attacker_actions(b, multidiscrete, discrete, decoded, const_cast<uint8_t*>(w->invalid), stream);
+    WrapperFinishArgs A;
+    int rc = finish_args(b, w, modifier, max_timesteps, auto_reset, keep, fresh, &A);      // (all checks before the first launch)
     if (rc) return rc;
-    if ((rc = mcbs_step_observe(b, decoded, const_cast<float*>(w->reward), const_cast<uint8_t*>(w->terminated), info, obs, stream))) return rc;
-    return mcbs_attacker_wrapper_finish(b, w, modifier, max_timesteps, auto_reset, keep, fresh, stream);
+    if (b->cfg.rng_kind == MCBS_RNG_TAPE && b->cfg.defender_kind != MCBS_DEFENDER_NONE && !b->tape)
+        return fail(MCBS_ESTATE, "rng_kind is TAPE but no draw tape was set (mcbs_set_draw_tape)");
+    if (!multidiscrete == !discrete) return fail(MCBS_EINVAL, "need exactly one action encoding");
+    hipStream_t st = (hipStream_t)stream;
+    const StepIO io = make_io(b, decoded, const_cast<float*>(w->reward), const_cast<uint8_t*>(w->terminated), info);
+    uint8_t* invalid = const_cast<uint8_t*>(w->invalid);
+    if (b->lds_topo) {                       // (developer switch: the staged variant keeps separate launches)
+        if ((rc = mcbs_decode_attacker_actions(b, multidiscrete, discrete, decoded, invalid, stream))) return rc;
+        if ((rc = launch_step<1>(b, io, st, "step (attacker phase)"))) return rc;
+    } else {
+        b->all_fresh = false;
+        if (b->S.packed) launch_decode_step1_nw<0>(b, io, multidiscrete, discrete, invalid, st);
+        else if (b->S.WT == 1) launch_decode_step1_nw<1>(b, io, multidiscrete, discrete, invalid, st);
+        else if (b->S.WT == 2) launch_decode_step1_nw<2>(b, io, multidiscrete, discrete, invalid, st);
+        else launch_decode_step1_nw<4>(b, io, multidiscrete, discrete, invalid, st);
+        if ((rc = launch_ok("decode + step (attacker phase)"))) return rc;
+    }
+    if ((rc = launch_obs(b, obs, st))) return rc;
+    if (b->lds_topo) {                       // (developer switch: the staged variant keeps the two separate launches)
+        if ((rc = launch_step<2>(b, io, st, "step (defender phase)"))) return rc;
+        hipLaunchKernelGGL(wrapper_finish_kernel, dim3((b->S.E + 255) / 256), dim3(256), 0, st, b->S, b->T, A);
+        return launch_ok("wrapper finish");
+    }
+    if (b->S.packed) launch_step2_finish_nw<0>(b, io, A, st);
+    else if (b->S.WT == 1) launch_step2_finish_nw<1>(b, io, A, st);
+    else if (b->S.WT == 2) launch_step2_finish_nw<2>(b, io, A, st);
+    else launch_step2_finish_nw<4>(b, io, A, st);
+    return launch_ok("step (defender phase) + wrapper finish");
 }
 
 extern "C" int mcbs_defender_wrapper_post(mcbs_batch* b, const mcbs_defender_wrapper_buffers* w, const mcbs_defender_wrapper_cfg* cfg, void* stream) {

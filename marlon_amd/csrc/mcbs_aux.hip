@@ -52,11 +52,8 @@ __global__ __launch_bounds__(128) void sample_kernel(DevState S, Topo T, const S
 
 // AttackerEnvWrapper.step's decode + out-of-range interception (attack_wrapper.py:255-308, :236-253) and
 // MaskedDiscreteAttackerWrapper._decode (action_masking.py:112-142), one lane per env.
-__global__ __launch_bounds__(256) void decode_kernel(DevState S, const StepCfg* __restrict__ Cp, uint32_t Nmax, uint32_t Cmax, const int64_t* md,
-                                                    const int64_t* discrete, int32_t* out, uint8_t* invalid) {
-    const StepCfg& C = *Cp;   // device copy: by value it would push the arguments past 256 bytes (profiles/round1_notes.md)
-    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= S.E) return;
+__device__ __forceinline__ void decode_body(const DevState& S, const StepCfg& C, uint32_t Nmax, uint32_t Cmax, const int64_t* md, const int64_t* discrete,
+                                            int32_t* out, uint8_t* invalid, uint32_t e) {
     const int64_t nd = (int64_t)(S.h0[e].z & 0xFFFFu);
     int64_t kind, a = 0, b = 0, c = 0, d = 0;
     if (md) {
@@ -79,12 +76,20 @@ __global__ __launch_bounds__(256) void decode_kernel(DevState S, const StepCfg* 
         const bool is_c = idx < connect_size, is_l = !is_c && idx < connect_size + local_size;     // selects, no branches (see above)
         const int64_t rel = is_c ? idx : (is_l ? idx - connect_size : idx - connect_size - local_size);
         const int64_t inner = is_c ? Cm : (is_l ? L : R);
-        const int64_t x0 = rel % inner, q = rel / inner;
-        const int64_t qp = q / P;
+        int64_t x0, q, qp, qn, qm, qr;
+        if (idx >= 0 && idx < (1ll << 31)) {               // every index a policy can emit: the same quotients in 32-bit arithmetic
+            const uint32_t r32 = (uint32_t)rel, i32 = (uint32_t)inner, q32 = r32 / i32, p32 = (uint32_t)P, n32 = (uint32_t)N;
+            const uint32_t qp32 = q32 / p32;
+            x0 = r32 - q32 * i32; q = q32; qp = qp32; qr = q32 - qp32 * p32;
+            qn = is_c ? qp32 / n32 : q32 / n32; qm = is_c ? qp32 - (uint32_t)qn * n32 : q32 - (uint32_t)qn * n32;
+        } else {
+            x0 = rel % inner; q = rel / inner; qp = q / P; qr = q % P;
+            qn = is_c ? qp / N : q / N; qm = is_c ? qp % N : q % N;
+        }
         kind = is_c ? 2 : (is_l ? 0 : 1);
-        a = is_c ? qp / N : (is_l ? q : q / N);
-        b = is_c ? qp % N : (is_l ? x0 : q % N);
-        c = is_c ? q % P : (is_l ? 0 : x0);
+        a = is_l ? q : qn;
+        b = is_l ? x0 : qm;
+        c = is_c ? qr : (is_l ? 0 : x0);
         d = is_c ? x0 : 0;
     }
     bool ok;                                               // _action_in_discovered_range
@@ -95,6 +100,12 @@ __global__ __launch_bounds__(256) void decode_kernel(DevState S, const StepCfg* 
     o[0] = ok ? (int32_t)kind : MCBS_ACTION_SKIP;
     o[1] = (int32_t)a; o[2] = (int32_t)b; o[3] = (int32_t)c; o[4] = (int32_t)d;
     invalid[e] = ok ? 0 : 1;
+}
+
+__global__ __launch_bounds__(256) void decode_kernel(DevState S, const StepCfg* __restrict__ Cp, uint32_t Nmax, uint32_t Cmax, const int64_t* md,
+                                                    const int64_t* discrete, int32_t* out, uint8_t* invalid) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;   // (StepCfg by pointer: by value it would push the arguments past 256 bytes)
+    if (e < S.E) decode_body(S, *Cp, Nmax, Cmax, md, discrete, out, invalid, e);
 }
 
 // AttackerEnvWrapper.step's bookkeeping (attack_wrapper.py:286-354) for the whole batch: one launch instead of ~20 element-wise ones
@@ -169,20 +180,28 @@ __device__ __forceinline__ void copy_row_wave(const uint8_t* s, uint8_t* d, size
     }
 }
 
-__global__ __launch_bounds__(256) void wrapper_finish_kernel(DevState S, Topo T, mcbs_wrapper_buffers w, float modifier, int32_t max_timesteps,
-                                                            int auto_reset, mcbs_row_copies keep, mcbs_row_copies fresh, ObsDigest* digest,
-                                                            const ObsDigest* reset_digest) {
-    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u;
+struct WrapperFinishArgs {           // by value: kernel arguments of the two kernels below
+    mcbs_wrapper_buffers w;
+    float modifier;
+    int32_t max_timesteps, auto_reset, pad;
+    mcbs_row_copies keep, fresh;
+    ObsDigest* digest;
+    const ObsDigest* reset_digest;
+};
+
+// env e = this lane's env (e >= S.E: no env, the lane only helps with the copies); every lane of the wavefront must call it
+__device__ __forceinline__ void wrapper_finish_body(const DevState& S, const Topo& T, const WrapperFinishArgs& A, uint32_t e, uint32_t lane) {
+    const mcbs_wrapper_buffers& w = A.w;
     bool done = false;
     if (e < S.E) {                                       // wrapper_post_kernel, word for word
         const bool invalid = w.invalid[e] != 0;
         const float r = w.reward[e];
         const int32_t t = w.timesteps[e] + 1;
-        const float shaped = r + (invalid ? modifier : 0.0f);
+        const float shaped = r + (invalid ? A.modifier : 0.0f);
         const double ret = w.episode_returns[e] + (double)shaped;
-        const bool trunc = t >= max_timesteps;
+        const bool trunc = t >= A.max_timesteps;
         done = (w.terminated[e] != 0) || trunc;
-        const bool clear = done && auto_reset;
+        const bool clear = done && A.auto_reset;
         w.timesteps[e] = clear ? 0 : t;
         const int64_t nv = w.valid_action_count[e] + (invalid ? 0 : 1), ni = w.invalid_action_count[e] + (invalid ? 1 : 0);
         w.valid_action_count[e] = clear ? 0 : nv;
@@ -197,26 +216,51 @@ __global__ __launch_bounds__(256) void wrapper_finish_kernel(DevState S, Topo T,
         w.episode_length_out[e] = t;
         if (w.executed) w.executed[e] = invalid ? 0 : 1;
     }
-    uint64_t m = auto_reset ? __ballot(done) : 0ull;
+    uint64_t m = A.auto_reset ? __ballot(done) : 0ull;
     if (!m) return;
     const uint32_t wave_base = e - lane;
     while (m) {
         const uint32_t r = wave_base + (uint32_t)__builtin_ctzll(m);
         m &= m - 1;
-        for (uint32_t f = 0; f < keep.n; ++f) {          // the episode's last observation (its loads have landed before any store below is issued)
-            const size_t nb = keep.row_bytes[f];
-            copy_row_wave(static_cast<const uint8_t*>(keep.src[f]) + (size_t)r * nb, static_cast<uint8_t*>(keep.dst[f]) + (size_t)r * nb, nb, lane);
+        for (uint32_t f = 0; f < A.keep.n; ++f) {        // the episode's last observation (its loads have landed before any store below is issued)
+            const size_t nb = A.keep.row_bytes[f];
+            copy_row_wave(static_cast<const uint8_t*>(A.keep.src[f]) + (size_t)r * nb, static_cast<uint8_t*>(A.keep.dst[f]) + (size_t)r * nb, nb, lane);
         }
-        for (uint32_t f = 0; f < fresh.n; ++f) {         // the observation of a freshly reset env
-            const size_t nb = fresh.row_bytes[f];
-            copy_row_wave(static_cast<const uint8_t*>(fresh.src[f]), static_cast<uint8_t*>(fresh.dst[f]) + (size_t)r * nb, nb, lane);
+        for (uint32_t f = 0; f < A.fresh.n; ++f) {       // the observation of a freshly reset env
+            const size_t nb = A.fresh.row_bytes[f];
+            copy_row_wave(static_cast<const uint8_t*>(A.fresh.src[f]), static_cast<uint8_t*>(A.fresh.dst[f]) + (size_t)r * nb, nb, lane);
         }
         uint8_t* dst = S.body + (size_t)r * S.body_stride;
         for (uint32_t off = lane * 16u; off < S.body_stride; off += 64u * 16u)
             *reinterpret_cast<uint4*>(dst + off) = *reinterpret_cast<const uint4*>(S.init_body + off);
-        if (lane < 4u) reinterpret_cast<uint4*>(digest + r)[lane] = reinterpret_cast<const uint4*>(reset_digest)[lane];
+        if (lane < 4u) reinterpret_cast<uint4*>(A.digest + r)[lane] = reinterpret_cast<const uint4*>(A.reset_digest)[lane];
     }
     if (done) reset_header(S, T, e, S.episode[e] + 1u);
+}
+
+__global__ __launch_bounds__(256) void wrapper_finish_kernel(DevState S, Topo T, WrapperFinishArgs A) {
+    wrapper_finish_body(S, T, A, blockIdx.x * blockDim.x + threadIdx.x, threadIdx.x & 63u);
+}
+
+// The defender / goals half of a split step (step_kernel<2>) and the wrapper's finish in ONE launch: one-wavefront workgroups as
+// launch_step_v uses them (hot image through L1 / L2), lane = env in both halves; the finish reads the reward and the done flag its own
+// lane has just stored.  One graph node less per wrapper step.
+template <int WTP, int DEFK>
+__global__ __launch_bounds__(64) void step2_finish_kernel(DevState S, Topo T, const StepCfg* __restrict__ Cp, StepIO io, WrapperFinishArgs A) {
+    step_body<2, WTP, false, DEFK, false>(S, T, Cp, io, RollArgs{});
+    wrapper_finish_body(S, T, A, blockIdx.x * 64u + threadIdx.x, threadIdx.x);
+}
+
+// The wrappers' decode + interception and the attacker half of a split step (step_kernel<1>) in ONE launch: the lane decodes its env's
+// policy action into the engine row (and the invalid flag), stores it, and the step reads it back — same lane, same address.
+template <int WTP, int DEFK>
+__global__ __launch_bounds__(64) void decode_step1_kernel(DevState S, Topo T, const StepCfg* __restrict__ Cp, StepIO io, uint32_t Nmax, uint32_t Cmax,
+                                                         const int64_t* md, const int64_t* discrete, uint8_t* invalid) {
+    const uint32_t e = blockIdx.x * 64u + threadIdx.x;
+    if (e < S.E) decode_body(S, *Cp, Nmax, Cmax, md, discrete, const_cast<int32_t*>(io.actions), invalid, e);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // the row's stores stay ahead of the step's loads of it
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    step_body<1, WTP, false, DEFK, false>(S, T, Cp, io, RollArgs{});
 }
 
 // DefenderEnvWrapper.step's reward shaping (defend_wrapper.py:228-282), same order of fp64 operations as the host version it replaces
