@@ -431,7 +431,7 @@ int  mcbs_copy_rows_masked(mcbs_batch*, const mcbs_row_copies* copies, const uin
  *   mcbs_decode_attacker_actions (exactly one of multidiscrete [n_envs, 10] / discrete [n_envs]; `decoded` [n_envs, 5] receives the rows,
  *   w->invalid the interception flags), mcbs_step_observe (w->reward and w->terminated receive the environment's reward and done flags:
  *   the three `in` arrays of mcbs_wrapper_buffers are written by this call), mcbs_attacker_wrapper_finish.
- * Stream-ordered, no host synchronisation, hipGraph-capturable (five launches today). */
+ * Stream-ordered, no host synchronisation, hipGraph-capturable (three launches: decode + attacker half, observation, defender half + finish). */
 
 /* Everything an auto-resetting attacker wrapper does after the environment step, in ONE launch: mcbs_attacker_wrapper_post for every env
  * (n_done may be NULL here: nothing is counted; `executed` is written if given), then for the envs whose `dones` it has just set — what SB3's DummyVecEnv.step_wait does
