@@ -357,3 +357,38 @@ def test_wrapper_finish_equals_the_separate_launches_it_replaces(materialize_mas
             np.testing.assert_array_equal(x, y, err_msg=f"step {t}: environment state")
     assert ended >= 3 * E                                   # every env was reset inside the fused launch several times
     new.close(); old.close()
+
+
+def test_wrapper_step_with_the_staged_hot_image_equals_default(monkeypatch):
+    """mcbs_attacker_wrapper_step under MCBS_LDS_TOPO=1 (developer switch: hot image staged in LDS, the decode and the finish stay separate
+    launches) returns what the default three-launch step returns, auto-resets included."""
+    import torch
+    from marlon_amd import cyberbattle_env as ce
+    from marlon_amd.samples import toy_ctf
+    from marlon_amd.wrappers import AttackerVecEnv
+    E = 512
+
+    def mk():
+        return AttackerVecEnv(toy_ctf.new_environment(), E, maximum_node_count=12, maximum_total_credentials=10, attacker_goal=ce.AttackerGoal(own_atleast=3),
+                              max_timesteps=8, discrete=True, defender_agent=ce.ScanAndReimageCompromisedMachines(0.6, 2, 5), seed=5)
+    default = mk()
+    monkeypatch.setenv("MCBS_LDS_TOPO", "1")
+    staged = mk()
+    monkeypatch.delenv("MCBS_LDS_TOPO")
+    g = torch.Generator(device=default.engine.device).manual_seed(2)
+    for t in range(30):
+        m = default.action_masks()
+        assert torch.equal(m, staged.action_masks())
+        actions = torch.where(m, torch.rand(m.shape, generator=g, device=m.device), torch.full((1,), -1.0, device=m.device)).argmax(dim=1)
+        if t % 5 == 4:
+            actions[::3] = default.discrete_n - 1
+        a, b = default.step(actions), staged.step(actions)
+        for x, y in zip(a[1:4], b[1:4]):
+            assert torch.equal(x, y), f"step {t}"
+        for k in a[0]:
+            assert torch.equal(a[0][k], b[0][k]), f"step {t}: observation {k}"
+        for k in a[4]:
+            assert torch.equal(a[4][k], b[4][k]), f"step {t}: info {k}"
+        for k in default.terminal_observation:
+            assert torch.equal(default.terminal_observation[k], staged.terminal_observation[k]), f"step {t}: terminal observation {k}"
+    default.close(); staged.close()
