@@ -353,7 +353,11 @@ int  mcbs_decode_attacker_actions(mcbs_batch*, const int64_t* multidiscrete, con
  * In place: logits[e, a] = mask(e, a) ? logits[e, a] : fill, where mask is EXACTLY the mask_discrete the last observation call on this
  * batch (mcbs_step_observe / mcbs_observe / mcbs_observe_masked / mcbs_action_mask) wrote or would have written — it is rebuilt from the
  * per-env digest that call left (owned-source bits, discovered-node and cached-credential counts), so the N*N*P*C-byte mask itself need
- * not be requested from the observation at all.  Not available for MCBS_DEFENDER_RANDOM_EVENTS batches (MCBS_ESTATE). */
+ * not be requested from the observation at all.  Not available for MCBS_DEFENDER_RANDOM_EVENTS batches (MCBS_ESTATE).
+ * MCBS_ESTATE too while the digests cannot be trusted: before the first whole-batch observation, after mcbs_reset (whole batch: until the
+ * next observation; by mask: until mcbs_observe_masked has re-observed those envs) and after mcbs_set_state.  (The local-vulnerability
+ * block is read through the env's live discovery list, which only agrees with the digest's counts in those states.)
+ * Every launching entry point of this header selects the batch's device for its own duration (the caller's current device is restored). */
 #define MCBS_LOGITS_F32  0
 #define MCBS_LOGITS_BF16 1
 uint64_t mcbs_discrete_action_count(const mcbs_batch*);

@@ -47,6 +47,13 @@ static int fail(int code, const char* fmt, ...) {
         if (_e != hipSuccess) return fail(MCBS_EHIP, "%s failed: %s", #expr, hipGetErrorString(_e));      \
     } while (0)
 
+// Every entry point that launches on (or synchronises with) a batch's GPU runs with that GPU selected: a single process whose current
+// device differs from the batch's (PyTorch driving several GPUs) would otherwise launch on the wrong device or fail with an invalid
+// handle.  hipGetDevice is a thread-local read; hipSetDevice is only called when the devices differ, and the caller's device is put back.
+#define MCBS_ON_DEVICE(b)                                                                                                      \
+    DeviceGuard _dev_guard((b)->cfg.device);                                                                                   \
+    if (_dev_guard.err != hipSuccess) return fail(MCBS_EHIP, "cannot select device %d: %s", (b)->cfg.device, hipGetErrorString(_dev_guard.err))
+
 static FastDiv fast_div_host(uint32_t d);
 struct HotLayout { uint32_t node, desc, payload, auth, auth_words, triple, avail, fwlist, bytes; };
 
@@ -76,6 +83,10 @@ struct mcbs_batch {
     ObsDigest* digest = nullptr;
     ObsDigest* reset_digest = nullptr;   // the digest of a freshly reset env, captured by the first observation after a whole-batch reset
     bool all_fresh = true, reset_digest_ok = false;
+    // what mcbs_mask_logits may trust: 0 = no observation has written the per-env digests since the batch was created / wholly reset /
+    // given a state (mcbs_set_state); 1 = every env's digest is the one its last observation wrote; 2 = some envs were reset by mask
+    // since (their digests are stale until mcbs_observe_masked has re-observed them)
+    int digest_state = 0;
     const double* tape = nullptr;
     uint32_t tape_dps = 0;
     unsigned long long* stamps = nullptr;   // diagnostic builds: device buffer [waves][8]
@@ -486,8 +497,10 @@ static int launch_ok(const char* what) {
 
 extern "C" int mcbs_reset(mcbs_batch* b, const uint8_t* env_mask, void* stream) {
     if (!b) return fail(MCBS_EINVAL, "null batch");
+    MCBS_ON_DEVICE(b);
     hipLaunchKernelGGL(reset_kernel, dim3((b->S.E + 127) / 128), dim3(128), 0, (hipStream_t)stream, b->S, b->T, env_mask, 1);
     if (!env_mask) b->all_fresh = true;
+    b->digest_state = !env_mask ? 0 : (b->digest_state == 1 ? 2 : b->digest_state);
     return launch_ok("reset");
 }
 
@@ -587,6 +600,7 @@ static int launch_step(mcbs_batch* b, const StepIO& io, hipStream_t st, const ch
 extern "C" int mcbs_step(mcbs_batch* b, const int32_t* actions, float* reward, uint8_t* terminated,
                          const mcbs_info_buffers* info, void* stream) {
     if (!b || !actions || !reward || !terminated) return fail(MCBS_EINVAL, "null argument");
+    MCBS_ON_DEVICE(b);
     if (b->cfg.rng_kind == MCBS_RNG_TAPE && b->cfg.defender_kind != MCBS_DEFENDER_NONE && !b->tape)
         return fail(MCBS_ESTATE, "rng_kind is TAPE but no draw tape was set (mcbs_set_draw_tape)");
     hipStream_t st = (hipStream_t)stream;
@@ -603,6 +617,7 @@ extern "C" int mcbs_step(mcbs_batch* b, const int32_t* actions, float* reward, u
 // mcbs_step; what is saved is the per-launch cost between dependent launches (1.5 us of a 5.5 us step at 65 536 envs).
 extern "C" int mcbs_step_many(mcbs_batch* b, const int32_t* actions, float* reward, uint8_t* terminated, uint32_t n_steps, void* stream) {
     if (!b || !actions || !reward || !terminated) return fail(MCBS_EINVAL, "null argument");
+    MCBS_ON_DEVICE(b);
     if (n_steps == 0) return MCBS_OK;
     if (b->cfg.rng_kind == MCBS_RNG_TAPE && b->cfg.defender_kind != MCBS_DEFENDER_NONE)
         return fail(MCBS_ESTATE, "mcbs_step_many needs the Philox generator: a draw tape holds one step's draws");
@@ -622,6 +637,7 @@ extern "C" int mcbs_step_many(mcbs_batch* b, const int32_t* actions, float* rewa
 extern "C" int mcbs_rollout_random(mcbs_batch* b, int32_t valid, uint64_t seed, uint64_t first_step, uint32_t n_steps,
                                    int32_t* actions_out, float* reward, uint8_t* terminated, void* stream) {
     if (!b || !reward || !terminated) return fail(MCBS_EINVAL, "null argument");
+    MCBS_ON_DEVICE(b);
     if (n_steps == 0) return MCBS_OK;
     if (b->cfg.rng_kind == MCBS_RNG_TAPE && b->cfg.defender_kind != MCBS_DEFENDER_NONE)
         return fail(MCBS_ESTATE, "mcbs_rollout_random needs the Philox generator: a draw tape holds one step's draws");
@@ -648,7 +664,10 @@ static int capture_reset_digest(mcbs_batch* b, hipStream_t st, bool whole_batch)
 static int launch_obs_inner(mcbs_batch* b, const mcbs_obs_buffers* o, hipStream_t st, bool masks_only, const uint8_t* env_mask);
 static int launch_obs(mcbs_batch* b, const mcbs_obs_buffers* o, hipStream_t st, bool masks_only = false, const uint8_t* env_mask = nullptr) {
     const int rc = launch_obs_inner(b, o, st, masks_only, env_mask);
-    return rc ? rc : capture_reset_digest(b, st, !masks_only && !env_mask);
+    if (rc) return rc;
+    if (!env_mask) b->digest_state = 1;                       // every observation kernel (masks-only ones too) leaves the env's digest
+    else if (b->digest_state == 2) b->digest_state = 1;       // the envs reset by mask have been re-observed (the caller's protocol)
+    return capture_reset_digest(b, st, !masks_only && !env_mask);
 }
 
 static int launch_obs_inner(mcbs_batch* b, const mcbs_obs_buffers* o, hipStream_t st, bool masks_only, const uint8_t* env_mask) {
@@ -769,22 +788,26 @@ static int launch_masks(mcbs_batch* b, const mcbs_obs_buffers* o, hipStream_t st
 
 extern "C" int mcbs_observe(mcbs_batch* b, const mcbs_obs_buffers* obs, void* stream) {
     if (!b || !obs) return fail(MCBS_EINVAL, "null argument");
+    MCBS_ON_DEVICE(b);
     return launch_obs(b, obs, (hipStream_t)stream);
 }
 
 extern "C" int mcbs_observe_masked(mcbs_batch* b, const mcbs_obs_buffers* obs, const uint8_t* env_mask, void* stream) {
     if (!b || !obs) return fail(MCBS_EINVAL, "null argument");
+    MCBS_ON_DEVICE(b);
     return launch_obs(b, obs, (hipStream_t)stream, false, env_mask);
 }
 
 extern "C" int mcbs_action_mask(mcbs_batch* b, const mcbs_obs_buffers* masks, void* stream) {
     if (!b || !masks) return fail(MCBS_EINVAL, "null argument");
+    MCBS_ON_DEVICE(b);
     return launch_obs(b, masks, (hipStream_t)stream, true);
 }
 
 extern "C" int mcbs_step_observe(mcbs_batch* b, const int32_t* actions, float* reward, uint8_t* terminated,
                                  const mcbs_info_buffers* info, const mcbs_obs_buffers* obs, void* stream) {
     if (!b || !actions || !reward || !terminated || !obs) return fail(MCBS_EINVAL, "null argument");
+    MCBS_ON_DEVICE(b);
     if (b->cfg.rng_kind == MCBS_RNG_TAPE && b->cfg.defender_kind != MCBS_DEFENDER_NONE && !b->tape)
         return fail(MCBS_ESTATE, "rng_kind is TAPE but no draw tape was set (mcbs_set_draw_tape)");
     hipStream_t st = (hipStream_t)stream;
@@ -797,6 +820,7 @@ extern "C" int mcbs_step_observe(mcbs_batch* b, const int32_t* actions, float* r
 
 extern "C" int mcbs_attacker_wrapper_post(mcbs_batch* b, const mcbs_wrapper_buffers* w, float modifier, int32_t max_timesteps, void* stream) {
     if (!b || !w) return fail(MCBS_EINVAL, "null argument");
+    MCBS_ON_DEVICE(b);
     const void* const* p = reinterpret_cast<const void* const*>(w);
     for (size_t i = 0; i + 1 < sizeof(*w) / sizeof(void*); ++i)          // `executed` (the last member) is not written by this call
         if (!p[i]) return fail(MCBS_EINVAL, "mcbs_wrapper_buffers: every array but `executed` is required");
@@ -809,12 +833,14 @@ extern "C" int mcbs_attacker_wrapper_post(mcbs_batch* b, const mcbs_wrapper_buff
 extern "C" int mcbs_attacker_wrapper_clear(mcbs_batch* b, const mcbs_wrapper_buffers* w, void* stream) {
     if (!b || !w || !w->dones || !w->timesteps || !w->valid_action_count || !w->invalid_action_count || !w->episode_returns || !w->has_cyber_reward)
         return fail(MCBS_EINVAL, "null argument");
+    MCBS_ON_DEVICE(b);
     hipLaunchKernelGGL(wrapper_clear_kernel, dim3((b->S.E + 255) / 256), dim3(256), 0, (hipStream_t)stream, b->S.E, *w);
     return launch_ok("wrapper clear");
 }
 
 extern "C" int mcbs_copy_rows_masked(mcbs_batch* b, const mcbs_row_copies* copies, const uint8_t* env_mask, void* stream) {
     if (!b || !copies || !env_mask) return fail(MCBS_EINVAL, "null argument");
+    MCBS_ON_DEVICE(b);
     if (copies->n == 0) return MCBS_OK;
     if (copies->n > 8) return fail(MCBS_EINVAL, "at most eight arrays per call");
     for (uint32_t i = 0; i < copies->n; ++i) if (!copies->src[i] || !copies->dst[i]) return fail(MCBS_EINVAL, "null array");
@@ -847,6 +873,7 @@ extern "C" int mcbs_attacker_wrapper_finish(mcbs_batch* b, const mcbs_wrapper_bu
     WrapperFinishArgs A;
     const int rc = finish_args(b, w, modifier, max_timesteps, auto_reset, keep, fresh, &A);
     if (rc) return rc;
+    MCBS_ON_DEVICE(b);
     b->all_fresh = false;
     hipLaunchKernelGGL(wrapper_finish_kernel, dim3((b->S.E + 255) / 256), dim3(256), 0, (hipStream_t)stream, b->S, b->T, A);
     return launch_ok("wrapper finish");
@@ -884,6 +911,7 @@ extern "C" int mcbs_attacker_wrapper_step(mcbs_batch* b, const int64_t* multidis
                                           int32_t max_timesteps, int32_t auto_reset, const mcbs_row_copies* keep, const mcbs_row_copies* fresh,
                                           void* stream) {
     if (!b || !w || !decoded || !obs) return fail(MCBS_EINVAL, "null argument");
+    MCBS_ON_DEVICE(b);
     WrapperFinishArgs A;
     int rc = finish_args(b, w, modifier, max_timesteps, auto_reset, keep, fresh, &A);      // (all checks before the first launch)
     if (rc) return rc;
@@ -919,6 +947,7 @@ extern "C" int mcbs_attacker_wrapper_step(mcbs_batch* b, const int64_t* multidis
 
 extern "C" int mcbs_defender_wrapper_post(mcbs_batch* b, const mcbs_defender_wrapper_buffers* w, const mcbs_defender_wrapper_cfg* cfg, void* stream) {
     if (!b || !w || !cfg) return fail(MCBS_EINVAL, "null argument");
+    MCBS_ON_DEVICE(b);
     const void* const* p = reinterpret_cast<const void* const*>(w);
     for (size_t i = 0; i < sizeof(*w) / sizeof(void*); ++i) if (!p[i]) return fail(MCBS_EINVAL, "mcbs_defender_wrapper_buffers: every array is required");
     hipLaunchKernelGGL(defender_wrapper_post_kernel, dim3((b->S.E + 255) / 256), dim3(256), 0, (hipStream_t)stream, b->S.E, *w, *cfg);
@@ -927,6 +956,7 @@ extern "C" int mcbs_defender_wrapper_post(mcbs_batch* b, const mcbs_defender_wra
 
 extern "C" int mcbs_step_info(mcbs_batch* b, const mcbs_info_buffers* info, void* stream) {
     if (!b || !info) return fail(MCBS_EINVAL, "null argument");
+    MCBS_ON_DEVICE(b);
     StepIO io = make_io(b, nullptr, nullptr, nullptr, info);
     hipLaunchKernelGGL(info_kernel, dim3((b->S.E + 255) / 256), dim3(256), 0, (hipStream_t)stream, b->S, io);
     return launch_ok("info");
@@ -934,6 +964,7 @@ extern "C" int mcbs_step_info(mcbs_batch* b, const mcbs_info_buffers* info, void
 
 extern "C" int mcbs_sample_actions(mcbs_batch* b, int32_t valid, uint64_t seed, uint64_t step, int32_t* actions_out, void* stream) {
     if (!b || !actions_out) return fail(MCBS_EINVAL, "null argument");
+    MCBS_ON_DEVICE(b);
     hipLaunchKernelGGL(sample_kernel, dim3((b->S.E + 127) / 128), dim3(128), 0, (hipStream_t)stream, b->S, b->T, b->C_dev, (int)valid, seed, step,
                        b->cfg.maximum_node_count, b->cfg.maximum_total_credentials, actions_out);
     return launch_ok("sample");
@@ -942,6 +973,7 @@ extern "C" int mcbs_sample_actions(mcbs_batch* b, int32_t valid, uint64_t seed, 
 extern "C" int mcbs_decode_attacker_actions(mcbs_batch* b, const int64_t* multidiscrete, const int64_t* discrete,
                                             int32_t* actions_out, uint8_t* invalid_out, void* stream) {
     if (!b || !actions_out || !invalid_out || (!multidiscrete == !discrete)) return fail(MCBS_EINVAL, "need exactly one action encoding and both outputs");
+    MCBS_ON_DEVICE(b);
     hipLaunchKernelGGL(decode_kernel, dim3((b->S.E + 255) / 256), dim3(256), 0, (hipStream_t)stream, b->S, b->C_dev,
                        b->cfg.maximum_node_count, b->cfg.maximum_total_credentials, multidiscrete, discrete, actions_out, invalid_out);
     return launch_ok("decode");
@@ -966,10 +998,15 @@ extern "C" uint64_t mcbs_discrete_action_count(const mcbs_batch* b) {
 
 extern "C" int mcbs_mask_logits(mcbs_batch* b, void* logits, int32_t dtype, size_t row_stride, float fill, void* stream) {
     if (!b || !logits) return fail(MCBS_EINVAL, "null argument");
+    MCBS_ON_DEVICE(b);
     if (dtype != MCBS_LOGITS_F32 && dtype != MCBS_LOGITS_BF16) return fail(MCBS_EINVAL, "logits dtype must be MCBS_LOGITS_F32 or MCBS_LOGITS_BF16");
     if (b->cfg.defender_kind == MCBS_DEFENDER_RANDOM_EVENTS)
         return fail(MCBS_ESTATE, "mcbs_mask_logits: under ExternalRandomEvents a node's local-vulnerability mask changes with the defender's "
                                  "edits and is not part of the observation digest; use the materialised mask (mcbs_observe)");
+    if (b->digest_state != 1)
+        return fail(MCBS_ESTATE, b->digest_state == 0 ? "mcbs_mask_logits: no observation has been taken since the batch was created, wholly reset or given a state "
+                                                        "(the mask is rebuilt from the digest the last observation left per env)"
+                                                      : "mcbs_mask_logits: envs were reset by mask and not re-observed (mcbs_observe_masked) since");
     const uint64_t A64 = mcbs_discrete_action_count(b);
     if (A64 >= (1ull << 31)) return fail(MCBS_ELIMIT, "Discrete action space too large for one launch");
     if (row_stride < A64) return fail(MCBS_EINVAL, "row_stride %zu is shorter than the %llu Discrete actions", row_stride, (unsigned long long)A64);
@@ -1012,6 +1049,7 @@ static int launch_defender_obs(mcbs_batch* b, const mcbs_defender_obs* o, hipStr
 extern "C" int mcbs_defender_step(mcbs_batch* b, const int64_t* actions, uint8_t* valid, double* availability, uint8_t* evicted,
                                   const mcbs_defender_obs* obs, void* stream) {
     if (!b || !actions) return fail(MCBS_EINVAL, "null argument");
+    MCBS_ON_DEVICE(b);
     if (b->cfg.defender_kind != MCBS_DEFENDER_EXTERNAL) return fail(MCBS_ESTATE, "batch was not created with MCBS_DEFENDER_EXTERNAL");
     hipStream_t st = (hipStream_t)stream;
     b->all_fresh = false;
@@ -1026,6 +1064,7 @@ extern "C" int mcbs_defender_step(mcbs_batch* b, const int64_t* actions, uint8_t
 
 extern "C" int mcbs_defender_observe(mcbs_batch* b, const mcbs_defender_obs* obs, void* stream) {
     if (!b || !obs) return fail(MCBS_EINVAL, "null argument");
+    MCBS_ON_DEVICE(b);
     if (b->cfg.defender_kind != MCBS_DEFENDER_EXTERNAL) return fail(MCBS_ESTATE, "batch was not created with MCBS_DEFENDER_EXTERNAL");
     return launch_defender_obs(b, obs, (hipStream_t)stream);
 }
@@ -1173,6 +1212,7 @@ extern "C" int mcbs_set_state(mcbs_batch* b, const void* host_buf, size_t nbytes
     }
     HIP_TRY(hipMemcpy(b->arena, host.data(), b->arena_bytes, hipMemcpyHostToDevice));
     b->all_fresh = false;
+    b->digest_state = 0;
     return MCBS_OK;
 }
 
@@ -1193,6 +1233,7 @@ extern "C" int mcbs_timing_enable(mcbs_batch* b, int32_t on) {
 
 extern "C" int mcbs_timing_read(mcbs_batch* b, double* total_ms, uint64_t* launches) {
     if (!b) return fail(MCBS_EINVAL, "null batch");
+    MCBS_ON_DEVICE(b);
     for (size_t i = 0; i + 1 < b->ev_used; i += 2) {
         HIP_TRY(hipEventSynchronize(b->ev[i + 1]));
         float ms = 0.f;

@@ -92,3 +92,42 @@ def test_wrapper_without_materialised_masks():
         for k in o2:
             assert torch.equal(o1[k], o2[k]), f"step {t} obs {k}"
     full.close(); lean.close()
+
+
+def test_mask_logits_refuses_stale_digests():
+    """mcbs_mask_logits rebuilds the mask from the digest the last observation left per env (the local block through the live discovery
+    list): it must refuse (MCBS_ESTATE) while no observation has been taken — after creation, a whole-batch reset, mcbs_set_state — and
+    while envs reset by mask have not been re-observed; it works again after the matching observation."""
+    import torch
+    from marlon_amd import engine
+    from marlon_amd._abi import EnvSpec
+    from marlon_amd.flatten import flatten
+    from marlon_amd.samples import chainpattern
+    topo = flatten(chainpattern.new_environment(4))
+    eng = engine.BatchEngine(topo, EnvSpec(n_envs=64, maximum_node_count=6, maximum_total_credentials=6, attacker_goal=dict(own_atleast_percent=1.0)))
+    logits = torch.zeros((64, eng.discrete_action_count()), device=eng.device)
+    small = eng.alloc_obs(["scalars", "nodes_privilegelevel"])
+    with pytest.raises(engine.McbsError, match="no observation"):
+        eng.mask_logits(logits)
+    eng.observe(small)
+    eng.mask_logits(logits)
+    for t in range(5):
+        eng.step(eng.sample_actions(True, seed=1, step=t))
+    eng.mask_logits(logits)                                  # steps do not invalidate: the mask is the LAST OBSERVATION's by definition
+    mask = torch.zeros(64, dtype=torch.uint8, device=eng.device)
+    mask[::3] = 1
+    eng.reset(mask)
+    with pytest.raises(engine.McbsError, match="reset by mask"):
+        eng.mask_logits(logits)
+    eng.observe(small, env_mask=mask)
+    eng.mask_logits(logits)
+    hdr, nodes, order, cache = eng.get_state()
+    eng.set_state(hdr, nodes, order, cache)
+    with pytest.raises(engine.McbsError, match="no observation"):
+        eng.mask_logits(logits)
+    eng.observe(small)
+    eng.mask_logits(logits)
+    eng.reset()
+    with pytest.raises(engine.McbsError, match="no observation"):
+        eng.mask_logits(logits)
+    eng.close()

@@ -102,3 +102,28 @@ def test_vecenv_surface_is_importable_without_gpu_or_sb3():
     for cls in (vecenv.MarlonVecEnv, vecenv.DefenderVecEnvAdapter):
         for m in ("reset", "step_async", "step_wait", "step", "env_method", "get_attr", "env_is_wrapped", "seed", "close"):
             assert callable(getattr(cls, m)), (cls.__name__, m)
+
+
+def test_every_launching_entry_point_selects_the_batch_device():
+    """A process whose current device is not the batch's (PyTorch driving several GPUs) must not launch on the wrong GPU: every
+    extern "C" entry point of mcbs_api.hip that launches a kernel, enqueues a copy or synchronises takes MCBS_ON_DEVICE(b) (or a
+    DeviceGuard of its own) BEFORE the first such statement.  The one-GPU box cannot exercise two devices, so this is checked on
+    the source."""
+    src = open(os.path.join(REPO, "marlon_amd", "csrc", "mcbs_api.hip")).read()
+    heads = list(re.finditer(r'extern "C" (?:int|void|size_t|uint64_t|uint32_t|const char\*) (mcbs_[a-z_]+)\(', src))
+    assert len(heads) >= 30
+    device_work = re.compile(r"hipLaunchKernelGGL|launch_step|launch_obs|launch_masks|launch_defender_obs|launch_decode_step1|launch_step2_finish|"
+                             r"hipMemcpy|hipMemset|hipDeviceSynchronize|hipEventSynchronize|hipFree|hipMalloc|launch_wrapper")
+    checked = 0
+    for i, m in enumerate(heads):
+        body = src[m.end():heads[i + 1].start() if i + 1 < len(heads) else len(src)]
+        # cut at the end of the function: the first line that is just "}"
+        end = re.search(r"^}\s*$", body, flags=re.M)
+        body = body[:end.start()] if end else body
+        w = device_work.search(body)
+        if not w:
+            continue
+        g = re.search(r"MCBS_ON_DEVICE\(b\)|DeviceGuard guard\(", body)
+        assert g and g.start() < w.start(), f"{m.group(1)} touches the device before selecting the batch's device"
+        checked += 1
+    assert checked >= 25
