@@ -18,9 +18,14 @@ barrier / MAX / gathers and an all_gather of episode returns after the timed reg
 
 The timed region replays the K steps from a hipGraph (launch-bound inner loop captured once), bracketed by
 barrier + synchronize on both sides (barrier, synchronize, K steps, synchronize, barrier; every rank times its own K steps between the two
-synchronizes and the job's time is the MAX over ranks).  The dominant kernel's average launch duration is measured in the same process
-with HIP events on the launch stream bracketing that timed region (/ K; a per-launch event-pair figure from an eager
-replay of the same K steps is printed beside it as an upper bound) and reported as a fraction of the HBM roofline.
+synchronizes and the job's time is the MAX over ranks).  The W warm-up steps are a second captured graph replayed right before.  Before
+that, untimed, both graphs are replayed once as a REHEARSAL (their first launch uploads them; it also touches every page the steps use) and
+the engine is put back to its start state: the driver's `--steps 20` region is 0.1 ms of device work, so a first-launch cost of a few
+microseconds would otherwise be a tenth of it.  The dominant kernel's average launch duration is measured in the same process with HIP
+events on the launch stream bracketing that timed region (/ K) and reported as a fraction of the HBM roofline; every launch of that kernel
+this process makes is a graph replay of the same shape (the recording rollout runs as ONE mcbs_rollout_random launch — a different kernel —
+and the per-launch event-pair cross-check is behind --event-pairs), so `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-extras
+--no-cpu-baseline` reports the same regime (profiles/round3_bench_headline*.json).
 Beside the headline (never as `value`): `configs` — the step kernels of BASELINE.json's configs 3, 4 (one GPU's shard) and
 5 (one GPU's shard) timed the same way, with their roofline fraction from MEASURED HBM bytes (profiles/round2_step_*.json,
 tied to the kernel sources by a hash); `observe` — the observation tier; `cpu_baseline` — the CPU oracle (oracle/, a port of
@@ -63,6 +68,8 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU oracle sample: repeat the recorded steps until about this long (1 core; half of it on all cores)")
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of a hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--event-pairs", action="store_true", help="also replay the K steps eagerly with one HIP event pair per launch (cross-check; "
+                    "adds eager launches of the headline kernel to the process: leave off under rocprofv3)")
     ap.add_argument("--no-extras", action="store_true", help="skip the `configs` and `observe` legs (they run at N = 1 only)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the timing collectives for N>1 (nccl = RCCL; gloo is the "
                     "agreed fallback when RCCL cannot be brought up on every rank)")
@@ -139,15 +146,14 @@ def init_collectives(world: int, rank: int, local_rank: int, want: str, use_gpu:
 
 
 def load_traffic(name: str, kernel_prefix: str):
-    """Measured HBM bytes per launch of one kernel from profiles/round2_<name>.json (tools/profile_all.sh + tools/pmc_summary.py).
+    """Measured HBM bytes per launch of one kernel from profiles/round3_<name>.json (else round2_) (tools/profile_all.sh + tools/pmc_summary.py).
     Returns (bytes_per_launch or None, info dict).  A file taken on other kernel sources than the ones this tree builds is STALE:
     its figure is not used."""
     from tools import workloads as W
-    path = os.path.join(REPO, "profiles", f"round2_{name}.json")
+    path = next((q for q in (os.path.join(REPO, "profiles", f"{r}_{name}.json") for r in ("round3", "round2")) if os.path.exists(q)), None)
+    if path is None:
+        return None, {"file": f"profiles/round3_{name}.json", "status": "missing"}
     info = {"file": os.path.relpath(path, REPO)}
-    if not os.path.exists(path):
-        info["status"] = "missing"
-        return None, info
     try:
         d = json.load(open(path))
         k = next(k for k in d["kernels"] if k["kernel"].startswith(kernel_prefix) and k.get("hbm_bytes_per_launch") is not None)
@@ -201,8 +207,25 @@ def rehearse(args, world, rank, local_rank) -> int:
         gathered = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(gathered, mine)
         assert [float(g[0]) for g in gathered] == [float(r) for r in range(world)]
+    # the `configs` legs of a multi-rank run (configs 4 and 5: every rank its shard): one barrier-bracketed region and one gather of
+    # times per configuration, in the same order on every rank
+    cfg_rows = []
+    for i, name in enumerate(("config4", "config5") if world > 1 else ("config3", "config4", "config5")):
+        if world > 1:
+            dist.barrier()
+        c0 = time.perf_counter()
+        time.sleep(0.002 * (rank + 1))
+        el = time.perf_counter() - c0
+        if world > 1:
+            dist.barrier()
+            tt = torch.tensor([el], dtype=torch.float64)
+            allt = [torch.empty_like(tt) for _ in range(world)]
+            dist.all_gather(allt, tt)
+            el = max(float(x.item()) for x in allt)
+        cfg_rows.append({"name": name, "n_gpus": world, "ms_host_clock_max_over_ranks": el * 1e3, "env_steps_per_s": None})
     if rank == 0:
         print(json.dumps({"metric": METRIC, "value": None, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "configs": cfg_rows,
                           "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
                           "data": "synthetic", "rehearsal": "launcher and collectives only: no engine, no GPU, nothing measured",
                           "collective_backend": backend, "ranks_in_group": dist.get_world_size() if world > 1 else 1,
@@ -243,97 +266,51 @@ def main() -> int:
             dist.barrier(group=group)
 
     E, K, Wm = args.envs_per_gpu, args.steps, args.warmup
+
+    # ---- headline: 65 536 Chain-10 envs per GPU, attacker only ----
     eng, topo, spec, desc = W.make_engine("headline", n_envs=E, env_id_base=rank * E, device=f"cuda:{local_rank}",
                                           max_episode_steps=args.max_episode_steps, seed=12345)
-    dev = eng.device
-
-    # ---- untimed: record W+K batches of valid random actions into an HBM ring, then rewind ----
-    ring = torch.empty((Wm + K, E, 5), dtype=torch.int32, device=dev)
-    for t in range(Wm + K):
-        eng.sample_actions(True, seed=12345, step=t, out=ring[t])
-        eng.step(ring[t], with_info=False)
+    # untimed: W+K batches of valid random actions recorded into an HBM ring by ONE launch of the looping step kernel (the random agent
+    # sampled inside it: the actions mcbs_sample_actions(valid, seed, t) + mcbs_step would give, tests/test_gpu_parity.py)
+    ring = eng.rollout_random(Wm + K, valid=True, seed=12345, first_step=0, record_actions=True)[2]
     torch.cuda.synchronize()
-    eng.reset()          # back to the initial state: the replay below repeats the recorded trajectory exactly (attacker only: no draws)
-    rewards = torch.empty((K, E), dtype=torch.float32, device=dev)
-    dones = torch.empty((K, E), dtype=torch.uint8, device=dev)
-    lib, h = eng.lib, eng._h
+    leg = W.timed_leg(eng, ring, Wm, K, graph=not args.no_graph, barrier=barrier, restore=eng.rewind)
+    elapsed_mine, region_us, rewards, dones = leg["elapsed_s"], leg["region_us"], leg["rewards"], leg["dones"]
+    elapsed, per_rank = gather_times(elapsed_mine, world, coll_dev, group)
+    reward_sum_timed = rewards.double().sum(dim=0)          # per-env return over the K timed steps
+    done_cnt_timed = dones.long().sum(dim=0)                # per-env `terminated` flags raised in the K timed steps
+    n_done = int(done_cnt_timed.sum().item())
+    same = leg["rehearsal_equal"]
+    kernel_us = region_us
+    lib, h, dev = eng.lib, eng._h, eng.device
+    st = torch.cuda.current_stream().cuda_stream
 
     def launch(t_ring: int, t_out: int, stream: int) -> None:
         rc = lib.mcbs_step(h, ring[t_ring].data_ptr(), rewards[t_out].data_ptr(), dones[t_out].data_ptr(), None, stream)
         if rc != 0:
             raise RuntimeError(lib.mcbs_last_error().decode())
 
-    # ---- warm-up (untimed) ----
-    st = torch.cuda.current_stream().cuda_stream
-    for t in range(Wm):
-        launch(t, t % K, st)
-    torch.cuda.synchronize()
-
-    graph = None
-    if not args.no_graph:
-        # the K timed steps captured once into a hipGraph (ring / output addresses are fixed per step)
-        graph = torch.cuda.CUDAGraph()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            with torch.cuda.graph(graph, stream=side):
-                s = torch.cuda.current_stream().cuda_stream
-                for t in range(K):
-                    launch(Wm + t, t, s)
-        torch.cuda.current_stream().wait_stream(side)
+    pair_us = None
+    if args.event_pairs:
+        # cross-check (off by default: its K eager launches of the same kernel would mix a second regime into a rocprofv3 trace of
+        # this process): one HIP event pair around EACH launch, same K steps, eager, from the same start state.  The pair itself
+        # costs ~2 us per launch at this kernel size, so this figure is an upper bound
+        eng.reset()
+        for t in range(Wm):
+            launch(t, t % K, st)
         torch.cuda.synchronize()
-        # graph capture does not execute: state is still "after warm-up"
-
-    # ---- timed region: exactly K steps ----
-    barrier()
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()         # HIP events on the launch stream (torch's current stream IS the stream the K launches go to)
-    if graph is not None:
-        graph.replay()
-    else:
+        eng.timing_enable(True)
         for t in range(K):
             launch(Wm + t, t, st)
-    ev1.record()
-    torch.cuda.synchronize()
-    elapsed_mine = time.perf_counter() - t0           # this rank's K steps, device work drained; the MAX over ranks below is the job's time
-    barrier()                                         # (the closing barrier brackets the region; its own latency is not part of the K steps)
-    region_us = ev0.elapsed_time(ev1) * 1e3 / K          # device time per launch over the timed region, launch gaps included
-    elapsed, per_rank = elapsed_mine, [elapsed_mine]
-    if world > 1:
-        tt = torch.tensor([elapsed_mine], dtype=torch.float64, device=coll_dev)
-        allt = [torch.empty_like(tt) for _ in range(world)]
-        dist.all_gather(allt, tt, group=group)
-        per_rank = [float(x.item()) for x in allt]
-        mx = tt.clone()
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
-        elapsed = float(mx.item())
-
-    reward_sum_timed = rewards.double().sum(dim=0)          # per-env return over the K timed steps
-    done_cnt_timed = dones.long().sum(dim=0)                # per-env `terminated` flags raised in the K timed steps
-    n_done = int(done_cnt_timed.sum().item())
-
-    # ---- cross-check: one HIP event pair around EACH launch, same K steps, eager, from the same start state.  The pair
-    # itself costs ~2 us per launch at this kernel size, so this figure is an upper bound; `kernel_us` (the roofline's
-    # denominator) is the event-bracketed timed region / K, which is what rocprofv3's kernel trace agrees with ----
-    eng.reset()
-    for t in range(Wm):
-        launch(t, t % K, st)
-    torch.cuda.synchronize()
-    eng.timing_enable(True)
-    for t in range(K):
-        launch(Wm + t, t, st)
-    kernel_ms, launches = eng.timing_read()
-    eng.timing_enable(False)
-    pair_us = kernel_ms * 1e3 / max(1, launches)
-    kernel_us = region_us
-    same = bool(torch.equal(rewards.double().sum(dim=0), reward_sum_timed) and torch.equal(dones.long().sum(dim=0), done_cnt_timed))
+        kernel_ms, launches = eng.timing_read()
+        eng.timing_enable(False)
+        pair_us = kernel_ms * 1e3 / max(1, launches)
+        same = same and bool(torch.equal(rewards.double().sum(dim=0), reward_sum_timed) and torch.equal(dones.long().sum(dim=0), done_cnt_timed))
 
     # ---- extra, NOT the headline: the same K recorded steps through mcbs_step_many (one launch, no per-step launch cost) ----
     eng.reset()
-    for t in range(Wm):
-        launch(t, t % K, st)
+    if Wm:
+        eng.step_many(ring[:Wm])
     many_r = torch.empty((K, E), dtype=torch.float32, device=dev)
     many_d = torch.empty((K, E), dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
@@ -356,9 +333,11 @@ def main() -> int:
     if rank == 0:
         bytes_per_launch = float(B_STEP) * E
         achieved = bytes_per_launch / (kernel_us * 1e-6) / 1e9
-        traffic, tinfo = load_traffic("step_headline", "mcbs::step_kernel<0, 0, false, 0")
+        traffic, tinfo = load_traffic("step_headline", W.STEP_KERNEL["headline"])
         if traffic is not None and E != ENVS_PER_GPU:
             traffic, tinfo["status"] = None, "not applicable: counters were taken at 65 536 envs per launch"
+        binding = load_binding("step_headline", W.STEP_KERNEL["headline"])
+        layout_b = layout_bytes_per_env_step(topo.n_nodes)
         per_rank_value = [E * K / x for x in per_rank]
         result = {
             "metric": METRIC,
@@ -375,8 +354,10 @@ def main() -> int:
             "data": "synthetic",
             "config": {"workload": f"CyberBattleChain size=10, {E} envs per GPU, attacker-only, recorded valid random actions, "
                                    f"auto-reset, truncation at {args.max_episode_steps} steps",
-                       "envs_per_gpu": E, "launch": "hipGraph replay" if graph is not None else "eager",
-                       "episodes_ended_in_timed_region_rank0": n_done},
+                       "envs_per_gpu": E, "launch": "hipGraph replay" if not args.no_graph else "eager",
+                       "episodes_ended_in_timed_region_rank0": n_done,
+                       # where the host clock's region goes: the device's share (HIP events) and the host's calls around it
+                       "timed_region_breakdown_us_rank0": leg["host_breakdown"]},
             "collective_backend": backend, "ranks_in_group": world,
             "per_rank_ms_per_step": [x * 1e3 / K for x in per_rank],
             "n1_value_hint": sum(per_rank_value) / len(per_rank_value),     # what ONE GPU did in this run (mean over ranks): compare with the N = 1 line
@@ -386,10 +367,19 @@ def main() -> int:
                          "kernel": HEADLINE_KERNEL, "kernel_us": kernel_us, "launches_timed": K,
                          "kernel_us_event_pair_per_launch": pair_us,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "bytes_per_env_step": B_STEP,
+                         # what the packed layout itself loads and stores per env-step (the contract's 348 B model charges 64-byte node
+                         # rows and a 32-byte header this layout does not have): DESIGN.md section 4
+                         "layout_bytes_per_env_step": layout_b,
+                         "frac_layout": layout_b * E / (kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                          "frac_of_measured_traffic": None if traffic is None else traffic / (kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                         # what actually binds the launch: one wavefront per SIMD, its cycles mostly parked on memory (SQ counters of
+                         # the committed profile): latency, not bandwidth — the 10 MB of state are L2 / Infinity-Cache resident
+                         "binding": binding,
                          "replay_rewards_and_dones_equal_timed_region": same},
-            # scripted-sequence entry point (no reference counterpart): K steps in ONE launch; reported beside, never as, `value`
-            "step_many": {"us_per_step": many_us, "env_steps_per_s_rank0": E / (many_us * 1e-6), "rewards_and_dones_equal_timed_region": many_same},
+            # scripted-sequence entry point (no reference counterpart): K steps in ONE launch; reported beside, never as, `value`.
+            # Under the contract's 348 B model it exceeds the HBM peak (frac > 1): the state never leaves the caches between steps
+            "step_many": {"us_per_step": many_us, "env_steps_per_s_rank0": E / (many_us * 1e-6), "rewards_and_dones_equal_timed_region": many_same,
+                          "frac_by_348B_model": B_STEP * E / (many_us * 1e-6) / 1e9 / HBM_PEAK_GBS},
         }
     ring_cpu = None
     if rank == 0 and not args.no_cpu_baseline:
@@ -397,17 +387,33 @@ def main() -> int:
         ring_cpu = ring[:, :n].cpu().numpy()
         ref_sum, ref_done = reward_sum_timed[:n].cpu().numpy(), done_cnt_timed[:n].cpu().numpy().astype(np.int32)
     eng.close()
-    del ring, rewards, dones, many_r, many_d, graph
+    del ring, rewards, dones, many_r, many_d, leg
     torch.cuda.empty_cache()
 
-    # ---- beside the headline, N = 1 only: the other BASELINE.json configurations and the observation tier ----
-    if rank == 0 and world == 1 and not args.no_extras:
+    # ---- beside the headline, every rank: the step kernels of the other BASELINE.json configurations.  N = 1: configs 3, 4 (one GPU's
+    # shard) and 5 (one GPU's shard); N > 1: configs 4 and 5 are DEFINED as shards over the GPUs of a node, so every rank runs its own
+    # shard (global env ids rank * shard ..) inside the same barrier / synchronize / MAX-over-ranks bracket and rank 0 reports the
+    # aggregate env-steps/s ----
+    if not args.no_extras:
         try:
-            result["configs"] = extras_configs(W)
-            result["observe"] = extras_observe(W)
-            result["wrapper"] = extras_wrapper()
+            cfgs = extras_configs(W, world, rank, local_rank, barrier, lambda x: gather_times(x, world, coll_dev, group)[0])
+            if rank == 0:
+                result["configs"] = cfgs
         except Exception as exc:      # the headline stands on its own; an extras failure is reported, not hidden
-            result["extras_error"] = f"{type(exc).__name__}: {exc}"
+            if rank == 0:
+                result["extras_error"] = f"configs: {type(exc).__name__}: {exc}"
+            parity_ok = False
+    # ---- rank 0 only (the other ranks wait at the closing barrier): the headline kernel with episodes ending inside the timed
+    # region, the observation tier and the wrapper tier ----
+    if rank == 0 and not args.no_extras:
+        try:
+            result["headline_with_resets"] = extras_resets(W, E, K if K <= 1000 else 1000, Wm, f"cuda:{local_rank}", not args.no_graph)
+            parity_ok = parity_ok and result["headline_with_resets"]["rewards_dones_and_episodes_equal_rehearsal"]
+            if world == 1:
+                result["observe"] = extras_observe(W)
+                result["wrapper"] = extras_wrapper()
+        except Exception as exc:
+            result["extras_error"] = (result.get("extras_error", "") + f" rank-0 extras: {type(exc).__name__}: {exc}").strip()
             parity_ok = False
 
     if rank == 0 and ring_cpu is not None:
@@ -459,30 +465,129 @@ def main() -> int:
     return 0 if parity_ok else 3
 
 
-def extras_configs(W):
-    """Step kernels of BASELINE.json configs 3-5 (per-GPU shard for the 8-GPU ones): hipGraph replay of recorded valid actions on a
-    fresh engine, HIP events on the launch stream; roofline fraction from the MEASURED HBM bytes of the same kernel (two --pmc passes,
-    profiles/round2_step_<config>.json) — SURVEY 8(d)'s N*64/scan_frequency defender term is not used: the bit-mask / ring state never
-    moves the per-node rows it charges."""
+def gather_times(elapsed_mine: float, world: int, coll_dev, group):
+    """(MAX over ranks, every rank's time) of one timed region."""
+    if world == 1:
+        return elapsed_mine, [elapsed_mine]
+    import torch
+    import torch.distributed as dist
+    tt = torch.tensor([elapsed_mine], dtype=torch.float64, device=coll_dev)
+    allt = [torch.empty_like(tt) for _ in range(world)]
+    dist.all_gather(allt, tt, group=group)
+    per_rank = [float(x.item()) for x in allt]
+    return max(per_rank), per_rank
+
+
+def max_over_ranks(x: float, world: int, coll_dev, group) -> float:
+    return gather_times(x, world, coll_dev, group)[0]
+
+
+def layout_bytes_per_env_step(n_nodes: int) -> int:
+    """Bytes one env-step of the PACKED layout loads and stores (marlon_amd/csrc/mcbs_step.hip, level-1 loads and the store round;
+    the shared hot topology image is L1-resident and not counted).  Loads: header uint4 16 + action row 20 + discovery
+    order head 16 + credential cache head 32 + every 4-byte node row (48 for <= 12 nodes, else 64) + the eight sets as one uint4 16 +
+    {cum_reward, availability} 16.  Stores: the target's row 4 + sets 16 + header 16 + {cum_reward, availability} 16 + reward 4 +
+    terminated 1 (+ 1 B / 2 B per newly listed node / credential: < 1 per step on average, not counted)."""
+    return (16 + 20 + 16 + 32 + (48 if n_nodes <= 12 else 64) + 16 + 16) + (4 + 16 + 16 + 16 + 4 + 1)
+
+
+def load_binding(name: str, kernel_prefix: str):
+    """What binds the kernel, from the SQ counters of the committed profile (any round: the counters describe the kernel's structure)."""
+    for rnd in ("round3", "round2"):
+        path = os.path.join(REPO, "profiles", f"{rnd}_{name}.json")
+        try:
+            d = json.load(open(path))
+            k = next(k for k in d["kernels"] if k["kernel"].startswith(kernel_prefix) and k.get("wave_cycle_split"))
+        except Exception:
+            continue
+        w = k["wave_cycle_split"]
+        return {"what": "latency: one wavefront per SIMD, the launch lasts as long as one wavefront's chain of dependent memory accesses",
+                "waves_per_launch": k.get("waves_per_launch"), "simds": 1024,
+                "wave_cycles_parked_at_waitcnt": w.get("parked_at_waitcnt_or_barrier"), "issuing": w.get("issuing"),
+                "issue_stalled": w.get("issue_stalled"), "source": os.path.relpath(path, REPO)}
+    return {"what": "latency: one wavefront per SIMD (no SQ-counter profile found under profiles/)"}
+
+
+def extras_configs(W, world: int, rank: int, local_rank: int, barrier, max_over):
+    """Step kernels of BASELINE.json configs 3-5 (per-GPU shard for the 8-GPU ones), timed exactly like the headline (timed_leg: recorded
+    valid actions, rehearsed hipGraph replay, barrier + synchronize on both sides, HIP events on the launch stream, MAX over ranks).
+    N = 1: configs 3, 4 (one shard), 5 (one shard).  N > 1: configs 4 and 5, rank r running the shard of global env ids r * shard ..;
+    `env_steps_per_s` is then the aggregate over the N shards.  Roofline fraction from the MEASURED HBM bytes of the same kernel (two
+    --pmc passes, profiles/round*_step_<config>.json) — SURVEY 8(d)'s N*64/scan_frequency defender term is not used: the bit-mask /
+    ring state never moves the per-node rows it charges.  Every rank returns; rank 0's list is the one reported."""
+    import torch
     out = []
-    for name, K in (("config3", 300), ("config4", 300), ("config5", 300)):
-        ring = W.record_ring(name, K)
-        eng, topo, spec, desc = W.make_engine(name)
-        us, rewards, dones = W.graph_replay_us(eng, ring, K)
-        kern = "mcbs::step_kernel<0, "
-        traffic, tinfo = load_traffic(f"step_{name}", kern)
-        row = {"workload": f"{desc}, {eng.E} envs", "name": name, "envs": eng.E, "nodes": topo.n_nodes, "steps": K,
-               "us_per_step": us, "env_steps_per_s": eng.E / (us * 1e-6),
-               "reward_sum": float(rewards.double().sum()), "episodes_ended": int(dones.sum()),
+    names = (("config3", 300), ("config4", 300), ("config5", 300)) if world == 1 else (("config4", 300), ("config5", 300))
+    for name, K in names:
+        _, shard, _, _ = W.workload(name)
+        base = rank * shard
+        ring = W.record_ring(name, K, env_id_base=base, device=f"cuda:{local_rank}")
+        eng, topo, spec, desc = W.make_engine(name, env_id_base=base, device=f"cuda:{local_rank}")
+        # (an engine in its creation state replays the recorded trajectory exactly, defender draws included: Philox is keyed by
+        # (seed, global env id, episode, step); mcbs_rewind puts the episode counters back to 0 after the rehearsal)
+        leg = W.timed_leg(eng, ring, 0, K, graph=True, barrier=barrier, restore=eng.rewind)
+        elapsed = max_over(leg["elapsed_s"])
+        us = leg["region_us"]
+        rewards, dones = leg["rewards"], leg["dones"]
+        traffic, tinfo = load_traffic(f"step_{name}", W.STEP_KERNEL[name])
+        row = {"workload": f"{desc}, {eng.E} envs per GPU", "name": name, "envs_per_gpu": eng.E, "n_gpus": world, "nodes": topo.n_nodes, "steps": K,
+               "us_per_step": us, "ms_per_step_host_clock_max_over_ranks": elapsed * 1e3 / K,
+               "env_steps_per_s": world * eng.E * K / elapsed, "env_steps_per_s_by_events_rank0": eng.E / (us * 1e-6),
+               "reward_sum_rank0": float(rewards.double().sum()), "episodes_ended_rank0": int(dones.sum()),
+               "rehearsal_equal": leg["rehearsal_equal"], "kernel": tinfo.get("kernel"),
                "roofline": {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": traffic, "traffic_source": tinfo,
                             "achieved": None if traffic is None else traffic / (us * 1e-6) / 1e9,
                             "frac": None if traffic is None else traffic / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                             "bytes_per_env_step_measured": None if traffic is None else traffic / eng.E}}
         out.append(row)
         eng.close()
-        del ring, rewards, dones
-        import torch
+        del ring, rewards, dones, leg
         torch.cuda.empty_cache()
+    return out
+
+
+def extras_resets(W, E: int, K: int, Wm: int, device: str, graph: bool):
+    """The headline kernel with episodes ENDING inside the timed region.  The metric's step includes the auto-reset, but at
+    marlon's truncation (2 000 steps) no episode ends within a thousand steps of a fresh batch.  Same workload and kernel with truncation
+    at 100 steps and the envs' step counters staggered over 0..99 beforehand (mcbs_set_state), so that about 1 % of the envs are
+    truncated and re-initialised by the wave-cooperative reset tail in EVERY step.  Reported beside `value`, never as it."""
+    import numpy as np
+    import torch
+    trunc = 100
+    eng, topo, spec, desc = W.make_engine("headline", n_envs=E, device=device, max_episode_steps=trunc, seed=12345)
+    hdr, nodes, order, cache = eng.get_state()
+    hdr = hdr.copy()
+    hdr["step_count"] = (np.arange(E, dtype=np.int64) * 7919 % trunc).astype(hdr["step_count"].dtype)     # ages 0..99, scattered over the wavefronts
+
+    def restore():
+        eng.rewind()
+        eng.set_state(hdr, nodes, order, cache)
+
+    def episodes():
+        return eng.get_state()[0]["episode"].astype(np.int64)
+
+    restore()
+    ring = eng.rollout_random(Wm + K, valid=True, seed=12345, first_step=0, record_actions=True)[2]
+    torch.cuda.synchronize()
+    restore()
+    ep0 = episodes()
+    leg = W.timed_leg(eng, ring, Wm, K, graph=graph, barrier=lambda: None, restore=restore)
+    ended = int((episodes() - ep0).sum())               # resets since the restore before the timed pass: warm-up + timed steps
+    us = leg["region_us"]
+    # the same W+K steps through the looping kernel from the same start state: rewards, flags and episode counts must agree
+    restore()
+    if Wm:
+        eng.step_many(ring[:Wm])
+    mr, md = eng.step_many(ring[Wm:Wm + K])
+    torch.cuda.synchronize()
+    same = bool(leg["rehearsal_equal"] and torch.equal(mr, leg["rewards"]) and torch.equal(md, leg["dones"]) and int((episodes() - ep0).sum()) == ended)
+    out = {"workload": f"{desc}, {E} envs, truncation at {trunc} steps, step counters staggered: ~{100 // trunc} % of the envs end and are reset in every step",
+           "kernel": HEADLINE_KERNEL, "steps": K, "warmup": Wm, "us_per_step": us, "ms_per_step_host_clock": leg["elapsed_s"] * 1e3 / K,
+           "env_steps_per_s": E * K / leg["elapsed_s"], "episodes_ended": ended, "episodes_ended_per_step": ended / max(1, Wm + K),
+           "terminated_flags_in_timed_region": int(leg["dones"].sum()),
+           "frac_by_348B_model": B_STEP * E / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+           "rewards_dones_and_episodes_equal_rehearsal": same}
+    eng.close()
     return out
 
 

@@ -281,6 +281,12 @@ void mcbs_batch_destroy(mcbs_batch*);
  * device array env_mask[E] is non-zero (NULL = all). */
 int  mcbs_reset(mcbs_batch*, const uint8_t* env_mask, void* stream);
 
+/* Every env back to the state mcbs_batch_create left it in: mcbs_reset for the whole batch with the episode counters at 0 again
+ * (mcbs_reset advances them, so that an env's next episode draws fresh defender randomness: Philox is keyed by (seed, global env id,
+ * episode, step)).  The reference's counterpart is constructing the environment anew (env.py:470-566); used to replay a recorded
+ * trajectory from its start (bench.py, tools/). */
+int  mcbs_rewind(mcbs_batch*, void* stream);
+
 /* CyberBattleEnv.step (env.py:1145-1185) for all envs in one launch, observation excluded.
  * actions: device int32 [E,5] rows (kind, a, b, c, d):
  *     kind 0 local_vulnerability  (source, vuln)              -- action dict order of env.py:540-559

@@ -504,6 +504,15 @@ extern "C" int mcbs_reset(mcbs_batch* b, const uint8_t* env_mask, void* stream) 
     return launch_ok("reset");
 }
 
+extern "C" int mcbs_rewind(mcbs_batch* b, void* stream) {
+    if (!b) return fail(MCBS_EINVAL, "null batch");
+    MCBS_ON_DEVICE(b);
+    hipLaunchKernelGGL(reset_kernel, dim3((b->S.E + 127) / 128), dim3(128), 0, (hipStream_t)stream, b->S, b->T, (const uint8_t*)nullptr, 0);
+    b->all_fresh = true;
+    b->digest_state = 0;
+    return launch_ok("rewind");
+}
+
 extern "C" int mcbs_set_draw_tape(mcbs_batch* b, const double* tape, uint32_t draws_per_step) {
     if (!b) return fail(MCBS_EINVAL, "null batch");
     b->tape = tape;

@@ -21,7 +21,7 @@ LIB_PATH = os.path.join(_HERE, "libmcbs.so")
 
 EXPORTS = [
     "mcbs_last_error", "mcbs_abi_version", "mcbs_topology_create", "mcbs_topology_destroy", "mcbs_batch_create",
-    "mcbs_batch_destroy", "mcbs_reset", "mcbs_step", "mcbs_step_observe", "mcbs_observe", "mcbs_observe_masked", "mcbs_action_mask", "mcbs_step_info",
+    "mcbs_batch_destroy", "mcbs_reset", "mcbs_rewind", "mcbs_step", "mcbs_step_observe", "mcbs_observe", "mcbs_observe_masked", "mcbs_action_mask", "mcbs_step_info",
     "mcbs_step_many", "mcbs_rollout_random", "mcbs_attacker_wrapper_post", "mcbs_attacker_wrapper_clear", "mcbs_defender_wrapper_post", "mcbs_sample_actions", "mcbs_decode_attacker_actions", "mcbs_defender_step", "mcbs_defender_observe", "mcbs_set_draw_tape", "mcbs_state_record_bytes", "mcbs_get_state", "mcbs_set_state",
     "mcbs_timing_enable", "mcbs_timing_read", "mcbs_mask_logits", "mcbs_discrete_action_count", "mcbs_copy_rows_masked", "mcbs_attacker_wrapper_finish", "mcbs_attacker_wrapper_step",
 ]
@@ -55,6 +55,7 @@ def load_library(path: Optional[str] = None):
     lib.mcbs_batch_create.argtypes = [C.c_void_p, C.POINTER(BatchCfg), C.POINTER(C.c_void_p)]
     lib.mcbs_batch_destroy.argtypes = [C.c_void_p]
     lib.mcbs_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.mcbs_rewind.argtypes = [C.c_void_p, C.c_void_p]
     lib.mcbs_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(InfoBuffers), C.c_void_p]
     lib.mcbs_step_many.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     lib.mcbs_attacker_wrapper_post.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int32, C.c_void_p]
@@ -193,6 +194,10 @@ class BatchEngine:
             env_mask = env_mask.to(device=self.device, dtype=self.torch.uint8).contiguous()
             ptr = env_mask.data_ptr()
         _check(self.lib, self.lib.mcbs_reset(self._h, ptr, self._stream()), "mcbs_reset")
+
+    def rewind(self) -> None:
+        """Every env back to the state right after creation (episode counters 0): a recorded trajectory replays exactly, defender draws included."""
+        _check(self.lib, self.lib.mcbs_rewind(self._h, self._stream()), "mcbs_rewind")
 
     def set_draw_tape(self, tape) -> None:
         t = self.torch

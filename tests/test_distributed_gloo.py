@@ -106,6 +106,9 @@ def test_bench_self_launches_ranks_when_invoked_plainly():
     assert line is not None and line["n_gpus"] == 2 and line["ranks_in_group"] == 2 and line["steps"] == 7 and line["warmup"] == 2
     assert line["self_launched"] is True and line["collective_backend"] == "gloo" and line["value"] is None
     assert len(line["per_rank_ms"]) == 2 and line["scaling"] == "weak"
+    # the 8-GPU configurations' legs run per rank at N > 1 (every rank its shard, MAX over ranks): config 3 is a one-GPU configuration
+    assert [c["name"] for c in line["configs"]] == ["config4", "config5"] and all(c["n_gpus"] == 2 for c in line["configs"])
+    assert all(c["ms_host_clock_max_over_ranks"] >= 4.0 for c in line["configs"])      # rank 1 sleeps 4 ms: the MAX, not rank 0's 2 ms
     assert line["metric"].startswith("env-steps/sec at 65536 envs, CyberBattleChain-10")
 
 

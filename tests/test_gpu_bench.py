@@ -30,6 +30,11 @@ def test_bench_line_contract_small_run():
     assert abs(r["achieved"] - 348 * 65536 / (r["kernel_us"] * 1e-6) / 1e9) / r["achieved"] < 1e-6       # algorithmic bytes / measured kernel time
     assert r["kernel_us"] <= b["ms_per_step"] * 1e3 * 1.05                                               # device time per launch fits the wall time per step
     assert r["replay_rewards_and_dones_equal_timed_region"] is True and b["step_many"]["rewards_and_dones_equal_timed_region"] is True
+    # the layout's own bytes beside the contract's 348 B model, and what binds the launch (latency, from the committed SQ counters)
+    assert r["layout_bytes_per_env_step"] == 221 and abs(r["frac_layout"] - r["frac"] * 221 / 348) < 1e-9
+    assert r["binding"]["what"].startswith("latency") and r["kernel_us_event_pair_per_launch"] is None
+    hr = b["headline_with_resets"]                       # the same kernel with ~1 % of the envs ending (and being re-initialised) per step
+    assert hr["episodes_ended"] >= 0.005 * 65536 * 50 and hr["rewards_dones_and_episodes_equal_rehearsal"] is True and hr["us_per_step"] > 0
     src = r["traffic_source"]
     assert src["status"] in ("current", "missing") or src["status"].startswith("stale"), src
     if src["status"] == "current":                                                                       # counters taken on THESE kernel sources
@@ -40,6 +45,7 @@ def test_bench_line_contract_small_run():
     assert c["kind"] == "port" and c["cores"] == 1 and c["rewards_and_dones_equal_gpu"] is True and c["all_cores"]["rewards_and_dones_equal_gpu"] is True
     assert c["reference_python"]["kind"] == "reference" and c["reference_python"]["value"] > 500
     assert [x["name"] for x in b["configs"]] == ["config3", "config4", "config5"] and all(x["us_per_step"] > 0 for x in b["configs"])
+    assert all(x["n_gpus"] == 1 and x["rehearsal_equal"] is True for x in b["configs"])
     assert {x["name"] for x in b["observe"]} >= {"headline", "headline_discrete", "headline_mask_logits", "config3"}
     w = b["wrapper"]
     assert len(w) == 3 and w[0]["last_reward_sum"] == w[1]["last_reward_sum"] == w[2]["last_reward_sum"]
@@ -61,4 +67,10 @@ def test_bench_two_ranks_on_one_gpu():
     assert len(b["per_rank_ms_per_step"]) == 2 and b["parity_ok"] is True and b["scaling"] == "weak"
     assert abs(b["ms_per_step"] - max(b["per_rank_ms_per_step"])) < 1e-9                                # MAX over ranks
     assert abs(b["value"] - 2 * 65536 * 60 / (b["ms_per_step"] * 60 * 1e-3)) / b["value"] < 1e-6       # aggregate over both ranks
-    assert "configs" not in b                                                                            # the extra legs run at N = 1 only
+    # BASELINE configs 4 and 5 are DEFINED as shards over the GPUs of a node: at N > 1 every rank runs its shard inside the same bracket
+    cf = b["configs"]
+    assert [x["name"] for x in cf] == ["config4", "config5"] and all(x["n_gpus"] == 2 and x["rehearsal_equal"] is True for x in cf)
+    assert [x["envs_per_gpu"] for x in cf] == [8192, 16384]
+    for x in cf:                                           # aggregate over both shards, from the MAX-over-ranks host clock
+        assert abs(x["env_steps_per_s"] - 2 * x["envs_per_gpu"] / (x["ms_per_step_host_clock_max_over_ranks"] * 1e-3)) / x["env_steps_per_s"] < 1e-6
+    assert b["headline_with_resets"]["episodes_ended"] > 0 and "observe" not in b and "extras_error" not in b

@@ -1,4 +1,5 @@
-"""GPU parity at BASELINE.json's OWN batch sizes (configs 3, 4 and 5; one GPU's shard for the 8-GPU ones).
+"""GPU parity at BASELINE.json's OWN batch sizes (the headline's 65 536 Chain-10 envs, configs 3, 4 and 5; one GPU's shard for the
+8-GPU ones).
 
 The launch shape of every kernel depends on the batch size (workgroup-size ladder, LDS budget of the hot image,
 grid-stride of the mask kernels), so the shapes the benchmark runs must meet a checker themselves, not only their
@@ -30,6 +31,12 @@ SMALL_OBS = ["scalars", "leaked_credentials", "credential_cache_matrix", "discov
 def _config(name):
     from marlon_amd import flatten as F, model
     from marlon_amd.samples import chainpattern, random_net, toy_ctf
+    if name == "headline_chain10_65536":
+        # BASELINE.json's metric shape: Chain size=10, 65 536 envs, attacker only (bounds 12 / 12, goal own 100 %); episodes truncated at
+        # 100 steps so that envs end — and are re-initialised by the wave-cooperative reset tail — inside the launches
+        # (env.py:1145-1185 step, 1187-1209 reset, DummyVecEnv's auto-reset)
+        return F.flatten(chainpattern.new_environment(10)), 65536, dict(
+            maximum_node_count=12, maximum_total_credentials=12, attacker_goal=dict(own_atleast_percent=1.0)), 230, 100
     if name == "config3_toyctf_16384":
         # BASELINE.json configs[2] / SURVEY 8(d): ToyCtf, ScanAndReimage(0.6, 2, 5), SLA 0.80, own_atleast 6, N 12, C 10
         return F.flatten(toy_ctf.new_environment()), 16384, dict(
@@ -50,7 +57,7 @@ def _config(name):
     raise KeyError(name)
 
 
-CONFIGS = ["config3_toyctf_16384", "config4_chain100_8192", "config5_random256_16384"]
+CONFIGS = ["headline_chain10_65536", "config3_toyctf_16384", "config4_chain100_8192", "config5_random256_16384"]
 
 
 def _spec(kw, n_envs, base, max_steps, seed=20260):
@@ -149,7 +156,7 @@ def test_full_shard_properties(name):
     disc_sorted = np.sort(np.where(order < N, order, 0xFFFF), axis=1)
     assert ((disc_sorted[:, 1:] != disc_sorted[:, :-1]) | (disc_sorted[:, 1:] == 0xFFFF)).all()   # discovery order has no duplicates
     assert (ends > 0).all()                                                        # every env ended (goal, SLA or truncation) at least once
-    assert (amin < 1.0).any() and tot.sum() > 0                                    # the defender re-imaged something somewhere
+    assert tot.sum() > 0 and ("defender" not in kw or (amin < 1.0).any())          # the defender re-imaged something somewhere
 
 
 def test_chain100_full_shard_observation():

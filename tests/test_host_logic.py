@@ -5,6 +5,7 @@ flow are checked here too; the same code against the HIP engine and the referenc
 What is pinned: DummyVecEnv / VecMonitor conventions (4-tuple, float32 rewards, bool dones, `TimeLimit.truncated = truncated and not
 terminated`, `terminal_observation` and `episode{r,l,t}` only on done, baseline_marlon_agent.py:100-167) and marl_algorithm.run_episode's
 rules (attacker then defender, stop on either done, max_steps, the defender's `-last attacker reward` after an attacker done)."""
+import os
 import types
 
 import numpy as np
@@ -163,3 +164,10 @@ def test_run_episode_stop_rule_and_reset_request_rule():
     assert solo["defender_rewards"] is None and solo["steps"] == 2 and solo["lengths"].tolist() == [2, 2, 2, 1]
     with pytest.raises(ValueError, match="auto_reset=False"):
         run_episode(ScriptedAttacker(a_r, a_te, a_tr, auto_reset=True), None)
+
+
+def test_no_unbound_names_in_host_code():
+    """bench.py, tools/ and the package run for real only on the GPU box; a misspelt or missing name must not wait for it."""
+    from tools import lint_names
+    problems = [(f, lint_names.unbound(os.path.join(lint_names.REPO, f))) for f in lint_names.DEFAULT]
+    assert not [p for p in problems if p[1]], [p for p in problems if p[1]]

@@ -1,15 +1,17 @@
 #!/usr/bin/env python3
 """One workload, a fixed number of launches, nothing else: the program rocprofv3 is pointed at (tools/profile_all.sh).
 
-    python3 tools/profile_run.py step:<workload> [K]      K mcbs_step launches (eager, recorded valid actions) on a fresh engine
+    python3 tools/profile_run.py step:<workload> [K]      K mcbs_step launches replayed from ONE hipGraph, twice (rehearsal + the replay bench.py
+                                                          times: tools/workloads.py timed_leg) — the regime bench.py measures; recorded valid actions
     python3 tools/profile_run.py obs:<workload> [K]       K mcbs_observe launches of the whole observation (reference dtypes)
     python3 tools/profile_run.py discrete:<workload> [K]  K mcbs_observe launches of the small fields + mask_discrete (MaskablePPO path)
     python3 tools/profile_run.py logits:<workload> [K]    K mcbs_mask_logits launches (on-device mask -> logits, no mask materialised)
     python3 tools/profile_run.py wrapper:<workload> [K]   K AttackerVecEnv.step calls (Discrete actions, no mask materialised, hipGraph replay)
 workload: headline | config2 | config3 | config4 | config5  (tools/workloads.py)
 
-The recording rollout uses a throw-away engine; its launches are in the trace too (same kernels, same shapes), which only adds
-samples to the per-kernel averages.  Prints one JSON line with the launch count so that the summariser can cross-check."""
+The recording rollout is ONE mcbs_rollout_random launch on a throw-away engine (the looping kernel, a different name), so every launch
+of the workload's step kernel in the trace is a graph replay.  Prints one JSON line with the launch count so that the summariser can
+cross-check."""
 import json
 import os
 import sys
@@ -70,12 +72,18 @@ ring = W.record_ring(name, K if what == "step" else 40)
 eng, topo, spec, desc = W.make_engine(name)
 out = dict(what=what, workload=name, envs=eng.E, launches=K, desc=desc)
 if what == "step":
-    rewards = torch.empty((K, eng.E), dtype=torch.float32, device=eng.device)
-    dones = torch.empty((K, eng.E), dtype=torch.uint8, device=eng.device)
-    st = torch.cuda.current_stream().cuda_stream
-    for t in range(K):
-        assert eng.lib.mcbs_step(eng._h, ring[t].data_ptr(), rewards[t].data_ptr(), dones[t].data_ptr(), None, st) == 0
-    torch.cuda.synchronize()
+    if os.environ.get("PROFILE_EAGER") == "1":          # the round-2 regime, for comparison: eager launches
+        rewards = torch.empty((K, eng.E), dtype=torch.float32, device=eng.device)
+        dones = torch.empty((K, eng.E), dtype=torch.uint8, device=eng.device)
+        st = torch.cuda.current_stream().cuda_stream
+        for t in range(K):
+            assert eng.lib.mcbs_step(eng._h, ring[t].data_ptr(), rewards[t].data_ptr(), dones[t].data_ptr(), None, st) == 0
+        torch.cuda.synchronize()
+        out["regime"] = "eager"
+    else:
+        us, rewards, dones = W.graph_replay_us(eng, ring, K)
+        out.update(regime="hipGraph replay (rehearsal + timed replay)", us_per_step_hip_events=us, step_kernel=W.STEP_KERNEL.get(name),
+                   step_kernel_launches=2 * K)
     out["reward_sum"] = float(rewards.double().sum())
 elif what in ("obs", "discrete"):
     fields = W.OBS_FIELDS if what == "obs" else W.OBS_FIELDS[:5] + ["mask_discrete"]

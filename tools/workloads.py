@@ -13,11 +13,22 @@ from __future__ import annotations
 import hashlib
 import os
 import subprocess
+import time
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 OBS_FIELDS = ["scalars", "leaked_credentials", "credential_cache_matrix", "discovered_nodes_properties", "nodes_privilegelevel",
               "mask_local", "mask_remote", "mask_connect"]
+
+
+# the fused-step kernel each workload's mcbs_step launches (rocprofv3's name without the argument list): profiles/ and bench.py agree on it
+STEP_KERNEL = {
+    "headline": "mcbs::step_kernel<0, 0, false, 0>",     # <whole step, packed sets, hot image through L1 / L2, no defender>
+    "config2": "mcbs::step_kernel<0, 0, false, 0>",
+    "config3": "mcbs::step_kernel<0, 0, false, 1>",      # packed, ScanAndReimage
+    "config4": "mcbs::step_kernel<0, 2, false, 1>",      # two words per set
+    "config5": "mcbs::step_kernel<0, 4, false, 1>",      # four words per set
+}
 
 
 def workload(name: str):
@@ -67,43 +78,97 @@ def make_engine(name: str, n_envs: int = 0, env_id_base: int = 0, device: str = 
 
 def record_ring(name: str, K: int, n_envs: int = 0, env_id_base: int = 0, device: str = "cuda:0", seed: int = 7):
     """K batches of valid random actions (the distribution of sample_valid_action) recorded by an untimed rollout of a
-    THROW-AWAY engine of the same workload: a fresh engine with the same seed then replays exactly the recorded trajectory,
-    defender draws included (Philox is keyed by (seed, global env id, episode, step); a reset would advance the episode)."""
+    THROW-AWAY engine of the same workload: a fresh (or rewound) engine with the same seed then replays exactly the recorded trajectory,
+    defender draws included (Philox is keyed by (seed, global env id, episode, step)).  ONE launch of the looping step kernel with
+    the random agent sampled inside it (mcbs_rollout_random: the actions mcbs_sample_actions(valid, seed, t) + mcbs_step would give) —
+    a different kernel from the one mcbs_step launches, so a rocprofv3 trace of the caller holds no recording launches of that one."""
     import torch
     eng, _, _, _ = make_engine(name, n_envs, env_id_base, device, seed=seed)
-    ring = torch.empty((K, eng.E, 5), dtype=torch.int32, device=eng.device)
-    for t in range(K):
-        eng.sample_actions(True, seed=seed, step=t, out=ring[t])
-        eng.step(ring[t], with_info=False)
+    ring = eng.rollout_random(K, valid=True, seed=seed, first_step=0, record_actions=True)[2]
     torch.cuda.synchronize()
     eng.close()
     return ring
 
 
 def graph_replay_us(eng, ring, K: int):
-    """us per mcbs_step launch: the K recorded steps captured into one hipGraph and replayed ONCE on a fresh engine, HIP events
-    on the launch stream around the replay.  Returns (us_per_step, rewards[K, E], dones[K, E])."""
+    """us per mcbs_step launch: the K recorded steps captured into one hipGraph, rehearsed once, the engine rewound, and replayed with
+    HIP events on the launch stream around the replay (timed_leg).  Returns (us_per_step, rewards[K, E], dones[K, E])."""
+    leg = timed_leg(eng, ring, 0, K, graph=True, barrier=lambda: None, restore=eng.rewind)
+    return leg["region_us"], leg["rewards"], leg["dones"]
+
+
+def timed_leg(eng, ring, Wm: int, K: int, graph: bool, barrier, restore):
+    """W warm-up steps (ring[:W]) then EXACTLY K timed steps (ring[W:W+K]) of mcbs_step on `eng`, from the state restore() leaves.
+    Both step sequences are captured as hipGraphs (graph=True) and REHEARSED once, untimed; restore() then puts the engine back to the
+    start state, the warm-up graph is replayed, and the K timed steps run between barrier + synchronize on both sides with HIP events
+    on the launch stream around them.  Returns elapsed_s (host clock, this rank), region_us (event time / K), rewards / dones [K, E]
+    of the timed replay, rehearsal_equal (the rehearsal's per-env sums equal the timed replay's: the replay is deterministic)."""
     import torch
-    rewards = torch.empty((K, eng.E), dtype=torch.float32, device=eng.device)
-    dones = torch.empty((K, eng.E), dtype=torch.uint8, device=eng.device)
+    E, dev = eng.E, eng.device
     lib, h = eng.lib, eng._h
-    g = torch.cuda.CUDAGraph()
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        with torch.cuda.graph(g, stream=side):
-            s = torch.cuda.current_stream().cuda_stream
-            for t in range(K):
-                if lib.mcbs_step(h, ring[t].data_ptr(), rewards[t].data_ptr(), dones[t].data_ptr(), None, s) != 0:
-                    raise RuntimeError(lib.mcbs_last_error().decode())
-    torch.cuda.current_stream().wait_stream(side)
+    rewards = torch.empty((K, E), dtype=torch.float32, device=dev)
+    dones = torch.empty((K, E), dtype=torch.uint8, device=dev)
+    wr = torch.empty((max(Wm, 1), E), dtype=torch.float32, device=dev)
+    wd = torch.empty((max(Wm, 1), E), dtype=torch.uint8, device=dev)
+
+    def run_steps(t0: int, n: int, r, d, stream: int) -> None:
+        for t in range(n):
+            if lib.mcbs_step(h, ring[t0 + t].data_ptr(), r[t].data_ptr(), d[t].data_ptr(), None, stream) != 0:
+                raise RuntimeError(lib.mcbs_last_error().decode())
+
+    def capture(t0: int, n: int, r, d):
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g, stream=side):
+                run_steps(t0, n, r, d, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        return g          # capture does not execute: the engine's state is untouched
+
+    if graph:
+        g_warm = capture(0, Wm, wr, wd) if Wm else None
+        g_timed = capture(Wm, K, rewards, dones)
+        warm = (lambda: g_warm.replay()) if Wm else (lambda: None)
+        timed = lambda: g_timed.replay()
+    else:
+        st = torch.cuda.current_stream().cuda_stream
+        warm = lambda: run_steps(0, Wm, wr, wd, st)
+        timed = lambda: run_steps(Wm, K, rewards, dones, st)
+
+    # rehearsal (untimed) from the start state, then back to it
+    restore()
+    warm()
+    timed()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    g.replay()
-    e1.record()
+    reh_r, reh_d = rewards.double().sum(dim=0), dones.long().sum(dim=0)
+    rewards.zero_()
+    dones.zero_()
+    restore()
+    # W untimed warm-up steps
+    warm()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e3 / K, rewards, dones
+    # timed region: exactly K steps
+    barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()         # HIP events on the launch stream (torch's current stream IS the stream the K launches go to)
+    t1 = time.perf_counter()
+    timed()
+    t2 = time.perf_counter()
+    ev1.record()
+    t3 = time.perf_counter()
+    torch.cuda.synchronize()
+    t4 = time.perf_counter()
+    elapsed = t4 - t0                                 # this rank's K steps, device work drained; the MAX over ranks is the job's time
+    barrier()                                         # (the closing barrier brackets the region; its own latency is not part of the K steps)
+    region_us = ev0.elapsed_time(ev1) * 1e3 / K       # device time per launch over the timed region, launch gaps included
+    same = bool(torch.equal(rewards.double().sum(dim=0), reh_r) and torch.equal(dones.long().sum(dim=0), reh_d))
+    host = {"event_record_us": (t1 - t0) * 1e6, "enqueue_us": (t2 - t1) * 1e6, "event_record2_us": (t3 - t2) * 1e6, "synchronize_us": (t4 - t3) * 1e6,
+            "device_region_us": region_us * K, "host_region_us": elapsed * 1e6}
+    return {"elapsed_s": elapsed, "region_us": region_us, "rewards": rewards, "dones": dones, "rehearsal_equal": same, "host_breakdown": host}
 
 
 def observe_us(eng, ring, fields, reps: int = 20, advance: int = 40):
