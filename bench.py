@@ -366,6 +366,9 @@ def main() -> int:
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tinfo,
                          "kernel": HEADLINE_KERNEL, "kernel_us": kernel_us, "launches_timed": K,
                          "kernel_us_event_pair_per_launch": pair_us,
+                         # the committed rocprofv3 kernel trace of THIS command (every launch of the kernel a graph replay of this shape):
+                         # its average duration and the fraction it gives; with the profiler attached bench.py's own kernel_us was ...
+                         "rocprof": load_rocprof("bench_headline", W.STEP_KERNEL["headline"], bytes_per_launch),
                          "algorithmic_bytes_per_launch": bytes_per_launch, "bytes_per_env_step": B_STEP,
                          # what the packed layout itself loads and stores per env-step (the contract's 348 B model charges 64-byte node
                          # rows and a 32-byte header this layout does not have): DESIGN.md section 4
@@ -489,6 +492,23 @@ def layout_bytes_per_env_step(n_nodes: int) -> int:
     {cum_reward, availability} 16.  Stores: the target's row 4 + sets 16 + header 16 + {cum_reward, availability} 16 + reward 4 +
     terminated 1 (+ 1 B / 2 B per newly listed node / credential: < 1 per step on average, not counted)."""
     return (16 + 20 + 16 + 32 + (48 if n_nodes <= 12 else 64) + 16 + 16) + (4 + 16 + 16 + 16 + 4 + 1)
+
+
+def load_rocprof(name: str, kernel_prefix: str, bytes_per_launch: float):
+    """Average duration of the kernel in the committed `rocprofv3 --kernel-trace --stats` summary of bench.py itself, the roofline
+    fraction that average gives, and what bench.py's own event bracket measured in that profiled run (the profiler's per-dispatch
+    time-stamping lengthens every launch a little, so the two figures of ONE run are the pair to compare)."""
+    path = os.path.join(REPO, "profiles", f"round3_{name}.json")
+    try:
+        d = json.load(open(path))
+        k = next(k for k in d["kernels"] if k["kernel"].startswith(kernel_prefix))
+    except Exception as exc:
+        return {"file": os.path.relpath(path, REPO), "status": f"missing or unreadable ({type(exc).__name__})"}
+    run = d.get("run", {})
+    return {"file": os.path.relpath(path, REPO), "command": d.get("command"), "calls": k["calls"], "avg_us": k["avg_us"], "min_us": k["min_us"],
+            "max_us": k["max_us"], "frac_by_avg_us": bytes_per_launch / (k["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "kernel_us_of_the_profiled_run": (run.get("roofline") or {}).get("kernel_us"), "ms_per_step_of_the_profiled_run": run.get("ms_per_step"),
+            "csrc_matches_this_tree": d.get("csrc_sha256") == __import__("tools.workloads", fromlist=["x"]).csrc_sha256()}
 
 
 def load_binding(name: str, kernel_prefix: str):

@@ -149,10 +149,13 @@ def timed_leg(eng, ring, Wm: int, K: int, graph: bool, barrier, restore):
     # W untimed warm-up steps
     warm()
     torch.cuda.synchronize()
-    # timed region: exactly K steps
+    # timed region: exactly K steps.  (The two HIP events are created and recorded once beforehand: torch creates the event object on its
+    # first record(), which cost 13 + 7 us of host time inside a region of 100 us of device work — tools/short_run_env.sh)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    ev1.record()
     barrier()
     torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()         # HIP events on the launch stream (torch's current stream IS the stream the K launches go to)
     t1 = time.perf_counter()
