@@ -12,6 +12,7 @@
 #include "mcbs.h"
 #include "mcbs_device.h"
 #include "mcbs_step.hip"
+#include "mcbs_step_coop.hip"
 #include "mcbs_obs.hip"
 #include "mcbs_aux.hip"
 #include "mcbs_defend.hip"
@@ -77,6 +78,7 @@ struct mcbs_batch {
     uint32_t* ere_lists_dev = nullptr;
     // developer switches, read ONCE at batch creation (getenv on every launch costs more than the launch itself)
     bool lds_topo = false, no_fused_masks = false, slow_masks = false, no_row_masks = false;
+    bool coop = false;              // mcbs_step runs the G-lanes-per-env kernel (mcbs_step_coop.hip): more than 64 nodes, sets of 2 or 4 words
     uint32_t step_block_override = 0;
     uint8_t* arena = nullptr;       // every per-env column + bodies + init body, one allocation
     size_t arena_bytes = 0;
@@ -375,6 +377,15 @@ extern "C" int mcbs_batch_create(const mcbs_topology* topo, const mcbs_batch_cfg
     S.wide = S.TW > 4u ? 1u : 0u;             // the cached-triple set does not fit 4 words: own column array (DevState::cach)
     if (!S.wide && S.TW > wt) wt = S.TW;
     S.WT = wt <= 1 ? 1 : (wt == 2 ? 2 : 4);
+    // large topologies: G = WT lanes per env (mcbs_step_coop.hip).  More than 64 nodes guarantees the list regions its level-1 loads
+    // cover (16 G discovery-order bytes, 32 G credential-cache bytes) lie inside the env's body; MCBS_NO_COOP=1: the one-lane kernel
+    // It pays while the one-lane kernel would leave SIMDs idle: measured on MI355X (profiles/round3_notes.md) 4.43 vs 4.96 us for
+    // 8 192 Chain-100 envs and 6.0 vs 7.4 us for 16 384 Random-256 envs, but 9.2 vs 9.0 us at 65 536 and 24.7 vs 22.9 us at 131 072 envs
+    // (the chip is full either way and the G lanes' redundant scalar work then costs issue slots): up to 512 one-lane wavefronts.
+    uint32_t coop_max_envs = 32768u;
+    if (const char* ov = getenv("MCBS_COOP_MAX_ENVS")) coop_max_envs = (uint32_t)strtoul(ov, nullptr, 10);   // experiments
+    b->coop = !S.packed && S.WT >= 2u && N > 64u && !S.wide && !b->lds_topo && !getenv("MCBS_NO_COOP") && E <= coop_max_envs &&
+              (cfg->defender_kind == MCBS_DEFENDER_NONE || cfg->defender_kind == MCBS_DEFENDER_SCAN_AND_REIMAGE);
     const size_t o_masks = take(S.packed ? 16ull * E : 8ull * M_COUNT * S.WT * E);
     const size_t o_cach = S.wide ? take(8ull * S.TW * E) : 0;
     const bool has_def = cfg->defender_kind != MCBS_DEFENDER_NONE;   // in-env or external: both re-image nodes
@@ -467,6 +478,22 @@ extern "C" int mcbs_batch_create(const mcbs_topology* topo, const mcbs_batch_cfg
     for (uint32_t n = 0; n < N; ++n) {
         if (ns[n].flags & MCBS_NODE_REIMAGABLE) C.reimagable[n >> 6] |= 1ull << (n & 63u);
         if (ns[n].avail_term != ns[0].avail_term) C.avail_uniform = 0u;
+    }
+
+    C.n_init = h->n_init_owned;
+    if (S.packed) {
+        if (S.body_stride > sizeof(C.init_image)) { (void)hipFree(b->arena); delete b; return fail(MCBS_ELIMIT, "packed body larger than its reset image"); }
+        memcpy(C.init_image, init.data(), S.body_stride);
+        uint16_t f[M_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const uint8_t* order0 = topo->host.data() + h->off_init_order;
+        for (uint32_t i = 0; i < h->n_init_owned; ++i) {
+            const uint32_t n = order0[i];
+            f[M_DISC] |= 1u << n; f[M_INST] |= 1u << n; f[M_EVER] |= 1u << n;
+            if (ns[n].priv0 & 1u) f[M_PLO] |= 1u << n;
+            if (ns[n].priv0 & 2u) f[M_PHI] |= 1u << n;
+        }
+        f[M_RUN] = (uint16_t)((1u << N) - 1u);
+        for (int q = 0; q < 4; ++q) C.init_packed[q] = (uint32_t)f[2 * q] | ((uint32_t)f[2 * q + 1] << 16);
     }
 
     e = hipMalloc(&b->C_dev, sizeof(StepCfg));
@@ -596,9 +623,22 @@ static void launch_step_nw(mcbs_batch* b, const StepIO& io, hipStream_t st, cons
     else launch_step_v<PHASE, WT, MCBS_DEFENDER_NONE, MANY>(b, io, st, roll);
 }
 
+template <int G>
+static void launch_step_coop(mcbs_batch* b, const StepIO& io, hipStream_t st) {
+    const uint32_t epw = 64u / G;
+    const dim3 grid((b->S.E + epw - 1u) / epw), block(64);
+    if (b->cfg.defender_kind == MCBS_DEFENDER_SCAN_AND_REIMAGE)
+        hipLaunchKernelGGL((step_coop_kernel<G, MCBS_DEFENDER_SCAN_AND_REIMAGE>), grid, block, 0, st, b->S, b->T, b->C_dev, io);
+    else hipLaunchKernelGGL((step_coop_kernel<G, MCBS_DEFENDER_NONE>), grid, block, 0, st, b->S, b->T, b->C_dev, io);
+}
+
 template <int PHASE, bool MANY = false>
 static int launch_step(mcbs_batch* b, const StepIO& io, hipStream_t st, const char* what, const RollArgs& roll = RollArgs{}) {
     b->all_fresh = false;
+    if (PHASE == 0 && !MANY && b->coop) {
+        if (b->S.WT == 2) launch_step_coop<2>(b, io, st); else launch_step_coop<4>(b, io, st);
+        return launch_ok(what);
+    }
     if (b->S.packed) launch_step_nw<PHASE, 0, MANY>(b, io, st, roll);       // WT 0: packed sets (one word of registers each)
     else if (b->S.WT == 1) launch_step_nw<PHASE, 1, MANY>(b, io, st, roll);
     else if (b->S.WT == 2) launch_step_nw<PHASE, 2, MANY>(b, io, st, roll);

@@ -514,7 +514,9 @@ __device__ __forceinline__ void step_body(const DevState& S, const Topo& T, cons
     double pending = 0.0;
     if (PHASE != 1) {
         h1 = S.h1[ec];
-        if (def_avail && C.rng_kind == MCBS_RNG_PHILOX) episode = S.episode[ec];
+        // (packed batches: always — the auto-reset of an env that ends needs episode + 1, and a load in the reset tail would sit behind
+        // the step's stores)
+        if (PK || (def_avail && C.rng_kind == MCBS_RNG_PHILOX)) episode = S.episode[ec];
     }
     if (PHASE == 2) pending = S.pending[ec];
 
@@ -715,7 +717,25 @@ __device__ __forceinline__ void step_body(const DevState& S, const Topo& T, cons
     }
     }
     STAMP(5);              // all stores of the step retired
-    if (PHASE != 1) {
+    if (PHASE != 1 && PK) {
+        // Packed batches: an env that just ended is re-initialised by its OWN lane with stores only — the body's reset image (<= 7 x 16
+        // bytes), the sets and the header come from the config through the scalar cache, the episode counter was fetched at level 1.
+        // (Round 2 let the whole wavefront copy the image from memory behind a fence, like the large layouts below: with ~1 % of the
+        // envs ending per step that cost every other wavefront a write-acknowledgement round trip — 6.06 vs 5.05 us per step.)
+        if (need_reset) {
+            uint4* dst = reinterpret_cast<uint4*>(S.body + (size_t)e * S.body_stride);
+            const uint32_t nv = S.body_stride >> 4;
+#pragma unroll
+            for (uint32_t i = 0; i < 7u; ++i)
+                if (i < nv) dst[i] = make_uint4(C.init_image[4 * i], C.init_image[4 * i + 1], C.init_image[4 * i + 2], C.init_image[4 * i + 3]);
+            reinterpret_cast<uint4*>(S.masks)[e] = make_uint4(C.init_packed[0], C.init_packed[1], C.init_packed[2], C.init_packed[3]);
+            if (S.ring) for (uint32_t s = 0; s < 16u; ++s) S.ring[(size_t)s * S.E + e] = 0ull;
+            S.h0[e] = make_uint4(0u, 0u, C.n_init, C.n_init);
+            S.h1[e] = make_double2(0.0, 1.0);
+            S.episode[e] = episode + 1u;
+            S.pending[e] = 0.0;
+        }
+    } else if (PHASE != 1) {
         // Envs that just ended are re-initialised by the whole wavefront: ballot the lanes that need it, then all
         // 64 lanes copy the reset image of one env at a time with 16-byte accesses (coalesced), instead of one
         // lane writing N rows serially.

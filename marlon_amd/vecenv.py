@@ -27,6 +27,7 @@ this calling sequence against traces of the reference's own wrapper classes.
 from __future__ import annotations
 
 import time
+import weakref
 from typing import Any, Dict, List, Optional, Sequence
 
 import numpy as np
@@ -39,7 +40,145 @@ def _to_numpy(x):
 
 
 class _InfoList(list):
-    """infos as SB3 expects them: a list of per-env dicts."""
+    """`infos` as SB3 consumes them — a sequence of one dict per env (`for info in infos: info.get("episode")`,
+    `infos[i]["terminal_observation"]`, baseline_marlon_agent.py:100-167, VecMonitor's `infos[:]`) — built ON DEMAND.
+
+    The step leaves the per-env info columns (availability, step count, flags, episode return / length) in ONE host block that one
+    asynchronous device-to-host copy fills; nothing is waited for and no Python object per env exists until somebody indexes or iterates
+    the list (one dict per env costs ~120 ns: 8 ms at 65 536 envs).  A trainer that consumes arrays reads
+    `columns()` / `ended()` instead and never builds a dict.  Envs whose episode ended carry `terminal_observation` and (with a monitor)
+    `episode` = {"r", "l", "t"}.  The list must be read before the NEXT step of its env (as SB3 does); if it is still alive and unread
+    when that step starts, the adapter loads it first."""
+
+    def __init__(self, n: int, block, ready, layout, term_obs_source, monitor: bool, elapsed: float, keys):
+        super().__init__()           # a real `list` (what VecEnv.step_wait is typed to return) whose storage is filled on first use
+        self._n, self._block, self._ready, self._layout = n, block, ready, layout
+        self._term_src, self._monitor, self._elapsed, self._keys = term_obs_source, monitor, elapsed, keys
+        self._cols: Optional[Dict[str, np.ndarray]] = None
+        self._ended: Optional[np.ndarray] = None
+        self._term_obs: Optional[Dict[str, np.ndarray]] = None
+        self._rank: Optional[Dict[int, int]] = None
+        self._dicts: Optional[List[Dict[str, Any]]] = None
+        self._some: Dict[int, Dict[str, Any]] = {}
+
+    # -- arrays (no per-env objects) --
+    def _load(self) -> None:
+        if self._cols is not None:
+            return
+        if self._ready is not None:
+            self._ready.synchronize()                       # the one D2H copy of this step's info block
+        raw = self._block.numpy() if hasattr(self._block, "numpy") else self._block
+        n, cols, off = self._n, {}, 0
+        for name, dt in self._layout:
+            w = np.dtype(dt).itemsize
+            cols[name] = raw[off:off + w * n].view(dt).copy()
+            if name in ("invalid_action", "valid_action"):
+                cols[name] = cols[name].astype(bool)
+            off += w * n
+        self._cols = cols
+        self._ended = np.flatnonzero((cols["terminated"] | cols["truncated"]) != 0)
+        if self._ended.size and self._term_src is not None:
+            self._term_obs = self._term_src(self._ended)    # rows of the envs that ended only
+        self._rank = {int(i): j for j, i in enumerate(self._ended)}
+        self._block = self._ready = self._term_src = None   # the host block goes back to the pinned-memory cache
+
+    def columns(self) -> Dict[str, np.ndarray]:
+        """The info fields as NumPy columns of num_envs entries each."""
+        self._load()
+        return self._cols
+
+    def ended(self) -> np.ndarray:
+        """Indices of the envs whose episode ended in this step (terminated or truncated)."""
+        self._load()
+        return self._ended
+
+    def terminal_observations(self) -> Optional[Dict[str, np.ndarray]]:
+        """The last observation of the episodes that ended, rows in the order of ended()."""
+        self._load()
+        return self._term_obs
+
+    # -- one dict per env --
+    def _make(self, i: int) -> Dict[str, Any]:
+        c = self._cols
+        d = {k: c[src][i].item() if not neg else not c[src][i].item() for k, src, neg in self._keys}
+        d["TimeLimit.truncated"] = bool(c["truncated"][i]) and not bool(c["terminated"][i])        # DummyVecEnv.step_wait
+        self._finish(d, i)
+        return d
+
+    def _finish(self, d: Dict[str, Any], i: int) -> None:
+        j = self._rank.get(i)
+        if j is None:
+            return
+        if self._term_obs is not None:
+            d["terminal_observation"] = {k: x[j] for k, x in self._term_obs.items()}
+        if self._monitor:          # VecMonitor.step_wait: episode return / length / wall time of the episode that just ended
+            d["episode"] = {"r": float(self._cols["episode_return"][i]), "l": int(self._cols["episode_length"][i]), "t": self._elapsed}
+
+    def _all(self) -> List[Dict[str, Any]]:
+        if self._dicts is None:
+            self._load()
+            c = self._cols
+            # plain Python lists first: per-element NumPy conversions would dominate at 65 536 envs
+            lists = [([not x for x in c[src].tolist()] if neg else c[src].tolist()) for _, src, neg in self._keys]
+            names = [k for k, _, _ in self._keys]
+            tl = ((c["truncated"] != 0) & (c["terminated"] == 0)).tolist()
+            ds = [dict(zip(names, vals)) for vals in zip(*lists)]
+            for d, t in zip(ds, tl):
+                d["TimeLimit.truncated"] = t
+            for i in self._ended.tolist():
+                self._finish(ds[i], i)
+            for i, d in self._some.items():                # dicts handed out (and possibly edited) before the bulk build stay the ones in the list
+                ds[i] = d
+            list.extend(self, ds)                          # from here on this IS an ordinary list of dicts
+            self._dicts = self
+        return self
+
+    def _filled(name):                                     # every other list method: fill the storage first, then behave like a list
+        def method(self, *args, **kwargs):
+            self._all()
+            return getattr(list, name)(self, *args, **kwargs)
+        method.__name__ = name
+        return method
+
+    for _name in ("__contains__", "__reversed__", "__add__", "__iadd__", "__mul__", "__imul__", "__delitem__", "__lt__", "__le__", "__gt__", "__ge__",
+                  "__ne__", "append", "extend", "insert", "pop", "remove", "clear", "index", "count", "sort", "reverse", "copy", "__reduce_ex__"):
+        locals()[_name] = _filled(_name)
+    del _name, _filled
+
+    def __len__(self) -> int:
+        return self._n
+
+    def __iter__(self):
+        self._all()
+        return list.__iter__(self)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice) or self._dicts is not None:
+            self._all()
+            return list.__getitem__(self, i)
+        i = int(i)
+        if i < 0:
+            i += self._n
+        if not 0 <= i < self._n:
+            raise IndexError("info index out of range")
+        d = self._some.get(i)
+        if d is None:
+            self._load()
+            d = self._some[i] = self._make(i)
+        return d
+
+    def __setitem__(self, i, value) -> None:
+        self._all()
+        list.__setitem__(self, i, value)
+
+    def __eq__(self, other) -> bool:
+        self._all()
+        return list.__eq__(self, other)
+
+    __hash__ = None
+
+    def __repr__(self) -> str:
+        return f"<infos of {self._n} envs, {'built' if self._dicts is not None else 'not built yet'}>"
 
 
 class MarlonVecEnv:
@@ -56,6 +195,7 @@ class MarlonVecEnv:
         self.monitor = bool(monitor)
         self.numpy_outputs = bool(numpy_outputs)
         self._actions = None
+        self._last_infos = None
         self._t_start = time.time()
         self.reset_infos: List[Dict[str, Any]] = [{} for _ in range(self.num_envs)]
         self.observation_space, self.action_space = self._spaces()
@@ -102,32 +242,52 @@ class MarlonVecEnv:
     def step_async(self, actions) -> None:
         self._actions = actions
 
+    _INFO_LAYOUT = (("network_availability", "<f8"), ("episode_return", "<f8"), ("rewards", "<f4"), ("step_count", "<i4"), ("episode_length", "<i4"),
+                    ("invalid_action", "u1"), ("terminated", "u1"), ("truncated", "u1"))
+    # info dict key -> (column, negated)
+    _INFO_KEYS = (("invalid_action", "invalid_action", False), ("cyber_step_executed", "invalid_action", True),
+                  ("network_availability", "network_availability", False), ("step_count", "step_count", False))
+
+    def _info_block(self, rewards, terminated, truncated, info):
+        """The step's per-env info columns gathered into ONE device buffer (one launch) and sent to pinned host memory by ONE asynchronous
+        copy; an event marks its arrival.  Replaces six pageable device-to-host copies per step."""
+        t = self.venv.torch
+        u8 = t.uint8
+        src = {"network_availability": info["network_availability"], "episode_return": info["episode_return"], "rewards": rewards,
+               "step_count": info["step_count"], "episode_length": info["episode_length"], "invalid_action": info["invalid_action"],
+               "terminated": terminated, "truncated": truncated}
+        dev = t.cat([src[name].contiguous().view(u8).reshape(-1) for name, _ in self._INFO_LAYOUT])
+        if not dev.is_cuda:          # (host tensors: the CPU stand-ins of tests/test_host_logic.py)
+            return dev, None
+        host = t.empty(dev.shape, dtype=u8, pin_memory=True)
+        host.copy_(dev, non_blocking=True)
+        ready = t.cuda.Event()
+        ready.record()
+        return host, ready
+
+    def _terminal_rows(self, ended: np.ndarray) -> Dict[str, np.ndarray]:
+        v = self.venv
+        sel = v.torch.as_tensor(ended, device=v.engine.device)
+        return {k: _to_numpy(x.index_select(0, sel)) for k, x in v.terminal_observation.items()}
+
     def step_wait(self):
         if self._actions is None:
             raise RuntimeError("step_wait() without step_async()")
         actions, self._actions = self._actions, None
         v = self.venv
+        last = self._last_infos() if self._last_infos is not None else None
+        if last is not None:
+            last._load()             # an unread info list of the previous step reads the wrapper's buffers before this step overwrites them
         obs, rewards, terminated, truncated, info = v.step(actions)
-        term, trunc = _to_numpy(terminated).astype(bool), _to_numpy(truncated).astype(bool)
-        dones = term | trunc
-        invalid = _to_numpy(info["invalid_action"]).astype(bool)
-        avail, steps = _to_numpy(info["network_availability"]), _to_numpy(info["step_count"])
-        # DummyVecEnv.step_wait: info["TimeLimit.truncated"] = truncated and not terminated
-        # (plain Python lists first: one dict per env is what SB3 wants, but per-element NumPy conversions would dominate at 65 536 envs)
-        infos = _InfoList({"invalid_action": iv, "cyber_step_executed": not iv, "network_availability": av, "step_count": sc, "TimeLimit.truncated": tl}
-                          for iv, av, sc, tl in zip(invalid.tolist(), avail.tolist(), steps.tolist(), (trunc & ~term).tolist()))
-        ended = np.flatnonzero(dones)
-        if ended.size:
-            sel = v.torch.as_tensor(ended, device=v.engine.device)
-            term_obs = {k: _to_numpy(x.index_select(0, sel)) for k, x in v.terminal_observation.items()}
-            ret, length = _to_numpy(info["episode_return"]), _to_numpy(info["episode_length"])
-            elapsed = round(time.time() - self._t_start, 6)
-            for j, i in enumerate(ended):
-                infos[i]["terminal_observation"] = {k: x[j] for k, x in term_obs.items()}
-                if self.monitor:      # VecMonitor.step_wait: episode return / length / wall time of the episode that just ended
-                    infos[i]["episode"] = {"r": float(ret[i]), "l": int(length[i]), "t": elapsed}
-        rew = _to_numpy(rewards).astype(np.float32) if self.numpy_outputs else rewards
-        return self._obs_out(obs), rew, (dones if self.numpy_outputs else (terminated | truncated) != 0), infos
+        host, ready = self._info_block(rewards, terminated, truncated, info)
+        infos = _InfoList(self.num_envs, host, ready, self._INFO_LAYOUT, self._terminal_rows, self.monitor, round(time.time() - self._t_start, 6),
+                          self._INFO_KEYS)
+        self._last_infos = weakref.ref(infos)
+        if not self.numpy_outputs:   # device tensors out, nothing waited for: the trainer consumes tensors and reads `infos` only if it wants to
+            return self._obs_out(obs), rewards, (terminated | truncated) != 0, infos
+        cols = infos.columns()       # (waits for the block: SB3 takes NumPy rewards / dones)
+        dones = (cols["terminated"] | cols["truncated"]) != 0
+        return self._obs_out(obs), cols["rewards"].astype(np.float32), dones, infos
 
     def step(self, actions):
         self.step_async(actions)
@@ -236,8 +396,8 @@ class DefenderVecEnvAdapter:
         term, trunc = _to_numpy(terminated).astype(bool), _to_numpy(truncated).astype(bool)
         dones = term | trunc
         valid, avail = _to_numpy(info["valid_action"]), _to_numpy(info["network_availability"])
-        infos = _InfoList({"valid_action": bool(va), "network_availability": av, "TimeLimit.truncated": tl}
-                          for va, av, tl in zip(valid.tolist(), avail.tolist(), (trunc & ~term).tolist()))
+        infos = [{"valid_action": bool(va), "network_availability": av, "TimeLimit.truncated": tl}
+                 for va, av, tl in zip(valid.tolist(), avail.tolist(), (trunc & ~term).tolist())]
         ended = np.flatnonzero(dones)
         if ended.size:
             ret, length = _to_numpy(self._ret), _to_numpy(self._len)

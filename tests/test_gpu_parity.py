@@ -411,3 +411,54 @@ def test_lds_staged_hot_image_equals_default(trace, monkeypatch):
             _compare_states(default.get_state(), staged.get_state(), f"{trace} step {t}")
     default.close()
     staged.close()
+
+
+@pytest.mark.parametrize("n_nodes,defender", [(100, True), (100, False), (256, True), (256, False)])
+def test_cooperative_kernel_equals_one_lane_kernel_and_oracle(n_nodes, defender, monkeypatch):
+    """Topologies with more than 64 nodes run mcbs_step on the G-lanes-per-env kernel (mcbs_step_coop.hip: G = 2 words per set at 100
+    nodes, 4 at 256); MCBS_NO_COOP=1 keeps the one-lane-per-env kernel of mcbs_step.hip on the same state layout.  Both engines and
+    the oracle are stepped side by side — every output of every step, the canonical state at intervals — on a batch that does not
+    fill its last wavefront, with valid, uniform and out-of-range actions, truncation and auto-reset inside the launch, with and
+    without the in-env defender (actions.py:325-423,524-606,700-746; defender.py:42-55)."""
+    from marlon_amd import flatten as F, model
+    from marlon_amd._abi import RNG_PHILOX, EnvSpec
+    from marlon_amd.samples import random_net
+    from oracle.oracle import Oracle
+    topo = F.flatten(random_net.build(model, n_nodes, 21))
+    E = 203
+    kw = dict(defender=("scan_and_reimage", 0.5, 3, 2), maintain_sla=0.3) if defender else {}
+    spec = EnvSpec(n_envs=E, maximum_node_count=n_nodes, maximum_total_credentials=max(1, len(topo.triples)),
+                   maximum_discoverable_credentials_per_action=8, attacker_goal=dict(own_atleast_percent=0.6), auto_reset=True,
+                   max_episode_steps=70, rng_kind=RNG_PHILOX, seed=99, env_id_base=1000, **kw)
+    coop = _engine().BatchEngine(topo, spec)
+    monkeypatch.setenv("MCBS_NO_COOP", "1")
+    lane = _engine().BatchEngine(topo, spec)
+    monkeypatch.delenv("MCBS_NO_COOP")
+    orc = Oracle(topo, spec)
+    ended = 0
+    for t in range(180):
+        a = coop.sample_actions(t % 6 != 5, seed=8, step=t)
+        if t % 11 == 3:
+            a[::5, 1] = n_nodes + 3                          # node index beyond the discovered nodes: the out-of-bound path
+        an = a.cpu().numpy()
+        r1, d1 = coop.step(a)
+        r2, d2 = lane.step(a)
+        o = orc.step(an)
+        ctx = f"random_net({n_nodes}) defender={defender} step {t}"
+        for name, x, y in (("reward", r1, r2), ("terminated", d1, d2)):
+            np.testing.assert_array_equal(x.cpu().numpy(), y.cpu().numpy(), err_msg=f"{ctx} {name}: cooperative vs one-lane kernel")
+        for k in coop.info:
+            np.testing.assert_array_equal(coop.info[k].cpu().numpy().view(np.uint8), lane.info[k].cpu().numpy().view(np.uint8), err_msg=f"{ctx} info {k}")
+        np.testing.assert_array_equal(r1.double().cpu().numpy(), o["reward"], err_msg=ctx + " reward vs oracle")
+        np.testing.assert_array_equal(d1.cpu().numpy(), o["terminated"], err_msg=ctx + " terminated vs oracle")
+        np.testing.assert_array_equal(coop.info["truncated"].cpu().numpy(), o["truncated"], err_msg=ctx + " truncated vs oracle")
+        np.testing.assert_array_equal(coop.info["out_of_bound"].cpu().numpy(), o["oob"], err_msg=ctx + " oob vs oracle")
+        np.testing.assert_array_equal(coop.info["network_availability"].cpu().numpy().view(np.uint64), o["availability"].view(np.uint64),
+                                      err_msg=ctx + " availability bits vs oracle")
+        ended += int(d1.sum()) + int(coop.info["truncated"].sum())
+        if t % 30 == 29 or t == 179:
+            _compare_states(coop.get_state(), lane.get_state(), ctx + " cooperative vs one-lane")
+            _compare_states(coop.get_state(), orc.get_state(), ctx + " vs oracle")
+    assert ended > E                                          # every env ended at least once, inside the launches
+    coop.close()
+    lane.close()

@@ -171,3 +171,34 @@ def test_no_unbound_names_in_host_code():
     from tools import lint_names
     problems = [(f, lint_names.unbound(os.path.join(lint_names.REPO, f))) for f in lint_names.DEFAULT]
     assert not [p for p in problems if p[1]], [p for p in problems if p[1]]
+
+
+def test_lazy_info_list_is_a_list_of_dicts_built_on_demand():
+    """MarlonVecEnv's infos (marlon_amd/vecenv.py _InfoList): a real `list` whose per-env dicts — DummyVecEnv's keys, VecMonitor's
+    `episode`, `terminal_observation` — only exist once somebody indexes or iterates it (SB3's _update_info_buffer does), built from
+    the step's info block; dicts handed out before the bulk build stay the ones in the list."""
+    import copy
+    import numpy as np
+    from marlon_amd.vecenv import MarlonVecEnv, _InfoList
+    layout = MarlonVecEnv._INFO_LAYOUT
+    cols = {"network_availability": np.array([1, .9, .8, 1, 1.]), "episode_return": np.array([0, 5, 0, 7, 0.]), "rewards": np.arange(5, dtype=np.float32),
+            "step_count": np.arange(5, dtype=np.int32), "episode_length": np.array([0, 3, 0, 4, 0], np.int32), "invalid_action": np.array([0, 1, 0, 0, 1], np.uint8),
+            "terminated": np.array([0, 1, 0, 0, 0], np.uint8), "truncated": np.array([0, 0, 0, 1, 0], np.uint8)}
+    raw = np.concatenate([cols[k].astype(dt).view(np.uint8) for k, dt in layout])
+    calls = []
+
+    def terminal_rows(ended):
+        calls.append(list(ended))
+        return {"x": np.arange(len(ended)) * 10}
+
+    infos = _InfoList(5, raw, None, layout, terminal_rows, True, 1.5, MarlonVecEnv._INFO_KEYS)
+    assert isinstance(infos, list) and len(infos) == 5 and not calls and list.__len__(infos) == 0      # nothing built, nothing fetched
+    d3 = infos[3]                                                                                        # one dict on demand
+    assert d3 == {"invalid_action": False, "cyber_step_executed": True, "network_availability": 1.0, "step_count": 3, "TimeLimit.truncated": True,
+                  "terminal_observation": {"x": 10}, "episode": {"r": 7.0, "l": 4, "t": 1.5}}
+    assert calls == [[1, 3]] and list.__len__(infos) == 0
+    d3["extra"] = 1
+    assert [i.get("episode") for i in infos] == [None, {"r": 5.0, "l": 3, "t": 1.5}, None, {"r": 7.0, "l": 4, "t": 1.5}, None]   # SB3's loop
+    assert list.__len__(infos) == 5 and infos[3] is d3 and infos[-1]["invalid_action"] is True and infos[1]["TimeLimit.truncated"] is False
+    assert "terminal_observation" not in infos[0] and infos.ended().tolist() == [1, 3] and infos.columns()["step_count"].tolist() == [0, 1, 2, 3, 4]
+    assert infos[:2] == [infos[0], infos[1]] and len(copy.copy(infos)) == 5 and infos == list(infos) and calls == [[1, 3]]

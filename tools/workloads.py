@@ -26,8 +26,8 @@ STEP_KERNEL = {
     "headline": "mcbs::step_kernel<0, 0, false, 0>",     # <whole step, packed sets, hot image through L1 / L2, no defender>
     "config2": "mcbs::step_kernel<0, 0, false, 0>",
     "config3": "mcbs::step_kernel<0, 0, false, 1>",      # packed, ScanAndReimage
-    "config4": "mcbs::step_kernel<0, 2, false, 1>",      # two words per set
-    "config5": "mcbs::step_kernel<0, 4, false, 1>",      # four words per set
+    "config4": "mcbs::step_coop_kernel<2, 1>",           # two words per set: two lanes per env (mcbs_step_coop.hip)
+    "config5": "mcbs::step_coop_kernel<4, 1>",           # four words per set: four lanes per env
 }
 
 
