@@ -17,6 +17,7 @@
 #include "mcbs_aux.hip"
 #include "mcbs_defend.hip"
 #include "mcbs_logits.hip"
+#include "mcbs_wrapper_fused.hip"
 
 using namespace mcbs;
 
@@ -78,6 +79,7 @@ struct mcbs_batch {
     uint32_t* ere_lists_dev = nullptr;
     // developer switches, read ONCE at batch creation (getenv on every launch costs more than the launch itself)
     bool lds_topo = false, no_fused_masks = false, slow_masks = false, no_row_masks = false;
+    bool no_fused_wrapper = false;  // MCBS_NO_FUSED_WRAPPER=1: mcbs_attacker_wrapper_step keeps its three launches (tests step both)
     bool coop = false;              // mcbs_step runs the G-lanes-per-env kernel (mcbs_step_coop.hip): more than 64 nodes, sets of 2 or 4 words
     uint32_t step_block_override = 0;
     uint8_t* arena = nullptr;       // every per-env column + bodies + init body, one allocation
@@ -323,6 +325,7 @@ extern "C" int mcbs_batch_create(const mcbs_topology* topo, const mcbs_batch_cfg
     b->cfg = *cfg;
     b->lds_topo = getenv("MCBS_LDS_TOPO") != nullptr; b->no_fused_masks = getenv("MCBS_NO_FUSED_MASKS") != nullptr;
     b->slow_masks = getenv("MCBS_SLOW_MASKS") != nullptr; b->no_row_masks = getenv("MCBS_NO_ROW_MASKS") != nullptr;
+    b->no_fused_wrapper = getenv("MCBS_NO_FUSED_WRAPPER") != nullptr;
     if (const char* ov = getenv("MCBS_STEP_BLOCK")) b->step_block_override = (uint32_t)atoi(ov);   // experiments only (64, 128 or 256)
     const uint32_t E = cfg->n_envs, N = h->n_nodes;
     DevState& S = b->S;
@@ -481,8 +484,8 @@ extern "C" int mcbs_batch_create(const mcbs_topology* topo, const mcbs_batch_cfg
     }
 
     C.n_init = h->n_init_owned;
-    if (S.packed) {
-        if (S.body_stride > sizeof(C.init_image)) { (void)hipFree(b->arena); delete b; return fail(MCBS_ELIMIT, "packed body larger than its reset image"); }
+    if (S.packed && S.body_stride <= sizeof(C.init_image)) {
+        C.init_image_ok = 1u;
         memcpy(C.init_image, init.data(), S.body_stride);
         uint16_t f[M_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};
         const uint8_t* order0 = topo->host.data() + h->off_init_order;
@@ -955,6 +958,66 @@ static void launch_decode_step1_nw(mcbs_batch* b, const StepIO& io, const int64_
     else launch_decode_step1_v<WT, MCBS_DEFENDER_NONE>(b, io, md, discrete, invalid, st);
 }
 
+// The whole wrapper step in ONE launch (mcbs_wrapper_fused.hip) when the batch and the request fit it: packed batch whose reset image is
+// held in the config, at most 16 nodes / cached credentials, no mask field, observation rows of whole 16-byte vectors, every requested
+// field paired with its terminal array and its reset row (auto_reset).  Returns 1 when it launched, 0 when the caller should run the
+// three launches, < 0 on error.
+static int try_fused_wrapper_step(mcbs_batch* b, const int64_t* multidiscrete, const int64_t* discrete, int32_t* decoded, const StepIO& io,
+                                  const mcbs_obs_buffers* o, const mcbs_wrapper_buffers* w, float modifier, int32_t max_timesteps, int32_t auto_reset,
+                                  const mcbs_row_copies* keep, const mcbs_row_copies* fresh, hipStream_t st) {
+    const mcbs_topo_header* h = b->topo->H();
+    const uint32_t Nm = b->cfg.maximum_node_count, Cm = b->cfg.maximum_total_credentials, K = b->cfg.maximum_discoverable_credentials_per_action;
+    if (b->no_fused_wrapper || b->lds_topo || b->no_fused_masks || !b->S.packed || !b->C.init_image_ok || b->S.N > 16u || Nm > 16u || Cm > 16u ||
+        h->n_triples > 15u || b->cfg.defender_kind == MCBS_DEFENDER_RANDOM_EVENTS || o->mask_local || o->mask_remote || o->mask_connect || o->mask_discrete)
+        return 0;
+    const uint32_t NP = b->C.n_props;
+    FusedArgs A{};
+    A.w = *w; A.modifier = modifier; A.max_timesteps = max_timesteps; A.auto_reset = auto_reset;
+    A.Nmax = Nm; A.Cmax = Cm; A.K = K; A.NP = NP;
+    A.md = multidiscrete; A.discrete = discrete; A.decoded = decoded;
+    int32_t* fields[FUSED_FIELDS] = {o->scalars, o->leaked_credentials, o->credential_cache_matrix, o->discovered_nodes_properties, o->nodes_privilegelevel};
+    const uint32_t dw[FUSED_FIELDS] = {7u, K * 4u, Cm * 2u, Nm * NP, Nm};
+    uint32_t off = 0;
+    for (uint32_t f = 0; f < FUSED_FIELDS; ++f) {
+        A.obs[f] = fields[f]; A.dwords[f] = dw[f]; A.fresh_off[f] = off;
+        const bool vec = f > 0 && dw[f] % 4u == 0 && !(f == 3 && NP < 4u);          // whole 16-byte vectors per env row, else dword by dword
+        A.d_u4[f] = fast_div_host(vec ? dw[f] / 4u : (dw[f] ? dw[f] : 1u));
+        if (!fields[f]) continue;
+        if (dw[f] == 0 || (vec && reinterpret_cast<uintptr_t>(fields[f]) % 16u != 0)) return 0;
+        if (auto_reset) {
+            int ki = -1, fi = -1;
+            for (uint32_t i = 0; keep && i < keep->n; ++i) if (keep->src[i] == fields[f] && keep->row_bytes[i] == 4ull * dw[f]) ki = (int)i;
+            for (uint32_t i = 0; fresh && i < fresh->n; ++i) if (fresh->dst[i] == fields[f] && fresh->row_bytes[i] == 4ull * dw[f]) fi = (int)i;
+            if (ki < 0 || fi < 0) return 0;
+            A.term[f] = static_cast<int32_t*>(keep->dst[ki]);
+            A.fresh[f] = static_cast<const int32_t*>(fresh->src[fi]);
+            if (vec && reinterpret_cast<uintptr_t>(A.term[f]) % 16u != 0) return 0;
+        }
+        off += (dw[f] + 3u) & ~3u;
+    }
+    if (off > FUSED_FRESH_DWORDS) return 0;
+    if (auto_reset) {          // every array the generic finish would copy must be one the fused kernel handles (no extra fields)
+        uint32_t n_fields = 0;
+        for (uint32_t f = 0; f < FUSED_FIELDS; ++f) n_fields += fields[f] ? 1u : 0u;
+        if ((keep ? keep->n : 0u) != n_fields || (fresh ? fresh->n : 0u) != n_fields) return 0;
+    }
+    A.dNP = fast_div_host(NP ? NP : 1u);
+    A.digest = b->digest; A.reset_digest = b->reset_digest;
+    A.triples = reinterpret_cast<const mcbs_triple*>(b->topo->dev + h->off_triple);
+    A.n_triples = h->n_triples;
+    b->all_fresh = false;
+    const dim3 grid((b->S.E + 63u) / 64u), block(FUSED_THREADS);
+    switch (b->cfg.defender_kind) {
+    case MCBS_DEFENDER_SCAN_AND_REIMAGE: hipLaunchKernelGGL((wrapper_fused_kernel<MCBS_DEFENDER_SCAN_AND_REIMAGE>), grid, block, 0, st, b->S, b->T, b->C_dev, io, A); break;
+    case MCBS_DEFENDER_EXTERNAL: hipLaunchKernelGGL((wrapper_fused_kernel<MCBS_DEFENDER_EXTERNAL>), grid, block, 0, st, b->S, b->T, b->C_dev, io, A); break;
+    default: hipLaunchKernelGGL((wrapper_fused_kernel<MCBS_DEFENDER_NONE>), grid, block, 0, st, b->S, b->T, b->C_dev, io, A); break;
+    }
+    const int rc = launch_ok("wrapper step (one launch)");
+    if (rc) return rc;
+    b->digest_state = 1;       // every env's digest was written (or, for an intercepted action, stands)
+    return 1;
+}
+
 extern "C" int mcbs_attacker_wrapper_step(mcbs_batch* b, const int64_t* multidiscrete, const int64_t* discrete, int32_t* decoded,
                                           const mcbs_info_buffers* info, const mcbs_obs_buffers* obs, const mcbs_wrapper_buffers* w, float modifier,
                                           int32_t max_timesteps, int32_t auto_reset, const mcbs_row_copies* keep, const mcbs_row_copies* fresh,
@@ -970,6 +1033,8 @@ extern "C" int mcbs_attacker_wrapper_step(mcbs_batch* b, const int64_t* multidis
     hipStream_t st = (hipStream_t)stream;
     const StepIO io = make_io(b, decoded, const_cast<float*>(w->reward), const_cast<uint8_t*>(w->terminated), info);
     uint8_t* invalid = const_cast<uint8_t*>(w->invalid);
+    if ((rc = try_fused_wrapper_step(b, multidiscrete, discrete, decoded, io, obs, w, modifier, max_timesteps, auto_reset, keep, fresh, st)) != 0)
+        return rc < 0 ? rc : MCBS_OK;
     if (b->lds_topo) {                       // (developer switch: the staged variant keeps separate launches)
         if ((rc = mcbs_decode_attacker_actions(b, multidiscrete, discrete, decoded, invalid, stream))) return rc;
         if ((rc = launch_step<1>(b, io, st, "step (attacker phase)"))) return rc;

@@ -247,7 +247,8 @@ __global__ __launch_bounds__(256) void wrapper_finish_kernel(DevState S, Topo T,
 // lane has just stored.  One graph node less per wrapper step.
 template <int WTP, int DEFK>
 __global__ __launch_bounds__(64) void step2_finish_kernel(DevState S, Topo T, const StepCfg* __restrict__ Cp, StepIO io, WrapperFinishArgs A) {
-    step_body<2, WTP, false, DEFK, false>(S, T, Cp, io, RollArgs{});
+    NoHook nh;
+    step_body<2, WTP, false, DEFK, false>(S, T, Cp, io, RollArgs{}, nh);
     wrapper_finish_body(S, T, A, blockIdx.x * 64u + threadIdx.x, threadIdx.x);
 }
 
@@ -260,7 +261,8 @@ __global__ __launch_bounds__(64) void decode_step1_kernel(DevState S, Topo T, co
     if (e < S.E) decode_body(S, *Cp, Nmax, Cmax, md, discrete, const_cast<int32_t*>(io.actions), invalid, e);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // the row's stores stay ahead of the step's loads of it
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    step_body<1, WTP, false, DEFK, false>(S, T, Cp, io, RollArgs{});
+    NoHook nh;
+    step_body<1, WTP, false, DEFK, false>(S, T, Cp, io, RollArgs{}, nh);
 }
 
 // DefenderEnvWrapper.step's reward shaping (defend_wrapper.py:228-282), same order of fp64 operations as the host version it replaces

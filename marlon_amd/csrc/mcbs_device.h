@@ -168,7 +168,9 @@ struct StepCfg {        // the parts of mcbs_batch_cfg the kernels read
     // lane: no load behind the step's stores, no wave-level copy, no fence (bench.py `headline_with_resets`)
     uint32_t init_image[28];
     uint32_t init_packed[4];
-    uint32_t n_init, pad_v[3];
+    uint32_t n_init;
+    uint32_t init_image_ok;  // 0: the body does not fit init_image (learned-defender / random-events state behind the rows): wave-level copy instead
+    uint32_t pad_v[2];
 };
 
 // mcbs_rollout_random: the looping step kernel samples each step's action itself; passed as a kernel argument of that variant only

@@ -124,6 +124,33 @@ __device__ __forceinline__ uint32_t dword_of(const uint4& r0, const uint4& r1, c
     return (uint32_t)((b3 ? s1 : s0) >> ((i & 1u) * 32u));
 }
 
+// entry i (< 16) of a 16-byte vector of u8 / of two 16-byte vectors of u16 := v (64-bit mask arithmetic, see byte_of)
+__device__ __forceinline__ void put_byte(uint4& v, uint32_t i, uint32_t x) {
+    uint64_t lo = (uint64_t)v.x | ((uint64_t)v.y << 32), hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
+    const uint32_t sh = (i & 7u) * 8u;
+    const uint64_t clr = ~(0xFFull << sh), val = (uint64_t)(x & 0xFFu) << sh;
+    if (i & 8u) hi = (hi & clr) | val; else lo = (lo & clr) | val;
+    v = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+}
+__device__ __forceinline__ void put_half(uint4& a, uint4& b, uint32_t i, uint32_t x) {
+    uint64_t w[4] = {(uint64_t)a.x | ((uint64_t)a.y << 32), (uint64_t)a.z | ((uint64_t)a.w << 32), (uint64_t)b.x | ((uint64_t)b.y << 32),
+                     (uint64_t)b.z | ((uint64_t)b.w << 32)};
+    const uint32_t sh = (i & 3u) * 16u, q = (i >> 2) & 3u;
+    const uint64_t clr = ~(0xFFFFull << sh), val = (uint64_t)(x & 0xFFFFu) << sh;
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; ++k) w[k] = k == q ? ((w[k] & clr) | val) : w[k];
+    a = make_uint4((uint32_t)w[0], (uint32_t)(w[0] >> 32), (uint32_t)w[1], (uint32_t)(w[1] >> 32));
+    b = make_uint4((uint32_t)w[2], (uint32_t)(w[2] >> 32), (uint32_t)w[3], (uint32_t)(w[3] >> 32));
+}
+
+// Hook points of step_body for kernels that wrap more work around the same step in the same launch (mcbs_wrapper_fused.hip); every
+// instantiation below that does not name a hook uses this empty one and compiles to exactly the code it had without them.
+struct NoHook {
+    static constexpr bool kAction = false;   // the action row is produced by the hook (decode of a policy action) instead of read from io.actions
+    static constexpr bool kObs = false;      // the hook assembles the observation between the attacker's action and the defender's turn
+    static constexpr bool kFinish = false;   // the hook runs after the step's stores (wrapper bookkeeping, auto-reset, streaming the observation)
+};
+
 // ------------------------------ per-lane working set ------------------------------
 template <int WT>
 struct Lane {
@@ -154,6 +181,9 @@ struct Lane {
     uint4 prw0 = {0, 0, 0, 0}, prw1 = {0, 0, 0, 0}, prw2 = {0, 0, 0, 0}, prw3 = {0, 0, 0, 0};
     uint32_t ptgt = 0xFFFFFFFFu, pword = 0;
     const uint8_t* ere_blob = nullptr;   // the topology blob (ExternalRandomEvents reads its cold tables)
+    // fused wrapper step (mcbs_wrapper_fused.hip, act<.., REC = true>): the heads of the two lists kept up to date in registers while the
+    // leak entries are appended, so that the observation can be assembled without reading the lists back
+    uint4 rec_dh = {0, 0, 0, 0}, rec_c0 = {0, 0, 0, 0}, rec_c1 = {0, 0, 0, 0};
 
     __device__ __forceinline__ const HotNode* NS(uint32_t n) const { return reinterpret_cast<const HotNode*>(tb + C.hot_node) + n; }
     __device__ __forceinline__ Row* row(uint32_t n) const { return reinterpret_cast<Row*>(body + S.off_rows) + n; }
@@ -178,7 +208,7 @@ struct Lane {
     //            `port` / `triple` = connect arguments (0 for exploits).  Every index is valid for every lane.
     // WIDE_OK = false: the batch cannot have a wide cached-triple set (packed layout); compiles its handling out.
     // DK: the batch's defender kind; MCBS_DEFENDER_RANDOM_EVENTS consults the env's own vulnerability / service / firewall state
-    template <bool WIDE_OK, int DK>
+    template <bool WIDE_OK, int DK, bool REC = false>
     __device__ __forceinline__ void act(bool X, double raw_nx, int kind, uint32_t src, uint32_t tgt, uint32_t col, uint32_t port, uint32_t triple) {
         const bool k2 = kind == 2;
         // ---- look-ups of both flavours (LDS) ----
@@ -307,6 +337,10 @@ struct Lane {
             } else new_c = creds & !rget<WT>(m[M_CACH], pt);
             disc_list()[n_disc] = (uint8_t)pn;
             cred_list()[n_creds] = (uint16_t)pt;
+            if (REC) {                                   // (packed batches: both lists have fewer than 16 entries)
+                put_byte(rec_dh, n_disc & 15u, pn);
+                put_half(rec_c0, rec_c1, n_creds & 15u, pt);
+            }
             uint64_t b0[WT], b1[WT], b2[WT];
             rbit<WT>(b0, pn, new_n); rbit<WT>(b1, pc, new_g); rbit<WT>(b2, pt & (WT * 64u - 1u), new_c && !wide);
 #pragma unroll
@@ -422,8 +456,8 @@ struct Lane {
 // DEFK: MCBS_DEFENDER_* (none / in-env ScanAndReimage / external learned defender).
 // MANY: the in-kernel step loop of mcbs_step_many / mcbs_rollout_random (step_many_kernel below); `roll` = the random agent of
 // mcbs_rollout_random (mode 0: actions are read from io.actions).
-template <int PHASE, int WTP, bool TOPO_LDS, int DEFK, bool MANY>
-__device__ __forceinline__ void step_body(const DevState& S, const Topo& T, const StepCfg* __restrict__ Cp, const StepIO& io, const RollArgs& roll) {
+template <int PHASE, int WTP, bool TOPO_LDS, int DEFK, bool MANY, class Hook>
+__device__ __forceinline__ void step_body(const DevState& S, const Topo& T, const StepCfg* __restrict__ Cp, const StepIO& io, const RollArgs& roll, Hook& hook) {
     constexpr bool PK = WTP == 0;           // packed batch: the eight sets are 16-bit fields of one uint4 per env
     constexpr int WT = PK ? 1 : WTP;
     const StepCfg& C = *Cp;   // in device memory: fields are fetched by scalar loads where they are used, not all up front
@@ -479,6 +513,8 @@ __device__ __forceinline__ void step_body(const DevState& S, const Topo& T, cons
             int32_t* o = const_cast<int32_t*>(iok.actions) + (size_t)e * 5;
             o[0] = ra[0]; o[1] = ra[1]; o[2] = ra[2]; o[3] = ra[3]; o[4] = ra[4];
         }
+    } else if constexpr (Hook::kAction) {
+        hook.load_action(ec);                            // the policy's own encoding; decoded below, once the header has landed
     } else if (PHASE != 2) {
         const uint32_t* ap = reinterpret_cast<const uint32_t*>(iok.actions) + (size_t)ec * 5;
         a03 = make_uint4(ap[0], ap[1], ap[2], ap[3]);
@@ -520,6 +556,7 @@ __device__ __forceinline__ void step_body(const DevState& S, const Topo& T, cons
     }
     if (PHASE == 2) pending = S.pending[ec];
 
+    if constexpr (Hook::kFinish) hook.level1(ec);                  // its own level-1 loads (wrapper counters ...) go out behind the step's
     STAMP_NOWAIT(1);   // level-1 loads issued
     uint32_t cL = C.L, cR = C.R, cP = C.P;
     // the goal / termination constants too (one pin for all, so that the loads go out together): fetched where they are used they
@@ -554,8 +591,11 @@ __device__ __forceinline__ void step_body(const DevState& S, const Topo& T, cons
 
     STAMP(2);          // level-1 loads and the LDS copy have landed
     bool need_reset = false;
+    float hk_reward = 0.0f;
+    bool hk_done = false;
     if (active) {   // (inactive lanes of the last wavefront still take part in the wave-level reset copy below)
     const uint32_t old_flags = h0.y;
+    if constexpr (Hook::kAction) hook.decode(S, C, h0, a03, a4);
     const bool ended = (old_flags & (F_DONE | F_TRUNC)) != 0;   // step after done: the reference raises RuntimeError
                                                                 // (env.py:1146-1147); the batch leaves the env untouched
     // skip actions (MCBS_ACTION_SKIP) leave the env untouched too; a split step remembers them in F_SKIP for phase 2
@@ -569,6 +609,7 @@ __device__ __forceinline__ void step_body(const DevState& S, const Topo& T, cons
 #pragma unroll
         for (int w = 0; w < WT; ++w) ln.m[k][w] = m0[k][w];
     ln.ere_blob = T.base;
+    if (Hook::kObs) { ln.rec_dh = dhead; ln.rec_c0 = chead0; ln.rec_c1 = chead1; }
     if (!PK && S.wide) {                                // this lane's LDS column for the wide cached-triple set, behind the hot image
         ln.wide_lds = reinterpret_cast<uint64_t*>(topo_lds + (TOPO_LDS ? C.hot_bytes / 16u : 0u)) + threadIdx.x;
         ln.wide_stride = bdim;
@@ -615,7 +656,7 @@ __device__ __forceinline__ void step_body(const DevState& S, const Topo& T, cons
         ln.props = pt & ROW_PROPS_MASK; ln.tags = (uint32_t)(pt >> 60);
         ln.ever = r0.z; ln.since = r0.w;
         STAMP(3);  // row landed
-        ln.template act<!PK, DEFK>(X, skip ? -1.0 : 0.0, kind, src, tgt, X ? (k0 ? a2 : (k1 ? cL + a3 : 0u)) : 0u, (X & k2) ? a3 : 0u, triple);
+        ln.template act<!PK, DEFK, Hook::kObs>(X, skip ? -1.0 : 0.0, kind, src, tgt, X ? (k0 ? a2 : (k1 ? cL + a3 : 0u)) : 0u, (X & k2) ? a3 : 0u, triple);
         // unchanged rows are written back as they were
         if (PK) {
             const uint32_t w = S.tiny_pack(ln.props, ln.tags, ln.ever, ln.since);
@@ -631,6 +672,8 @@ __device__ __forceinline__ void step_body(const DevState& S, const Topo& T, cons
                             ((uint32_t)ln.new_nodes << F_NEWNODES_SHIFT) | ((uint32_t)ln.new_creds << F_NEWCREDS_SHIFT);
         flags = live ? nf : ((PHASE == 1 && !ended && skip_env) ? (old_flags | F_SKIP) : old_flags);
         step += live ? 1u : 0u;
+        // the observation is assembled here: after the attacker's action, before the defender's turn (env.py:1153 vs 1156-1158)
+        if constexpr (Hook::kObs) hook.stage_obs(S, C, ln, flags, !skip_env);
     } else {
         oob = live & ((old_flags & F_OOB) != 0);
         ln.raw = pending;
@@ -688,6 +731,8 @@ __device__ __forceinline__ void step_body(const DevState& S, const Topo& T, cons
             if (iok.oob) iok.oob[e] = oob ? 1 : 0;
             if (iok.raw_reward) iok.raw_reward[e] = live ? (float)ln.raw : 0.0f;
             need_reset = (done | trunc) & (g_auto != 0);
+            hk_reward = (float)reward;
+            hk_done = live ? done : ((old_flags & F_DONE) != 0);
             flags |= (done ? F_DONE : 0u) | (trunc ? F_TRUNC : 0u);
             S.h0[e] = make_uint4(step, flags, ln.n_disc | (ln.n_creds << 16), ln.owned | (ln.dclk << 16));
             S.h1[e] = h1;
@@ -717,7 +762,7 @@ __device__ __forceinline__ void step_body(const DevState& S, const Topo& T, cons
     }
     }
     STAMP(5);              // all stores of the step retired
-    if (PHASE != 1 && PK) {
+    if (PHASE != 1 && PK && C.init_image_ok) {
         // Packed batches: an env that just ended is re-initialised by its OWN lane with stores only — the body's reset image (<= 7 x 16
         // bytes), the sets and the header come from the config through the scalar cache, the episode counter was fetched at level 1.
         // (Round 2 let the whole wavefront copy the image from memory behind a fence, like the large layouts below: with ~1 % of the
@@ -755,6 +800,7 @@ __device__ __forceinline__ void step_body(const DevState& S, const Topo& T, cons
             if (need_reset) reset_header(S, T, e, S.episode[e] + 1u);
         }
     }
+    if constexpr (Hook::kFinish) hook.finish(S, C, T, e, active, hk_reward, hk_done, episode);
     }   // steps of this launch
 #ifdef MCBS_DIAG
     STAMP(6);
@@ -770,14 +816,16 @@ __device__ __forceinline__ void step_body(const DevState& S, const Topo& T, cons
 // agent's parameters therefore travel only with the looping variant below, which is launched once per K steps.
 template <int PHASE, int WTP, bool TOPO_LDS, int DEFK>
 __global__ __launch_bounds__(256) void step_kernel(DevState S, Topo T, const StepCfg* __restrict__ Cp, StepIO io) {
-    step_body<PHASE, WTP, TOPO_LDS, DEFK, false>(S, T, Cp, io, RollArgs{});
+    NoHook nh;
+    step_body<PHASE, WTP, TOPO_LDS, DEFK, false>(S, T, Cp, io, RollArgs{}, nh);
 }
 
 // mcbs_step_many / mcbs_rollout_random: io.n_steps consecutive steps in one launch; `roll` is a kernel ARGUMENT (nothing in device
 // memory is patched per call, so launches on different streams or inside a stream capture cannot see each other's mode).
 template <int WTP, bool TOPO_LDS, int DEFK>
 __global__ __launch_bounds__(256) void step_many_kernel(DevState S, Topo T, const StepCfg* __restrict__ Cp, StepIO io, RollArgs roll) {
-    step_body<0, WTP, TOPO_LDS, DEFK, true>(S, T, Cp, io, roll);
+    NoHook nh;
+    step_body<0, WTP, TOPO_LDS, DEFK, true>(S, T, Cp, io, roll, nh);
 }
 
 } // namespace mcbs

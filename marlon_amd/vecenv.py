@@ -118,13 +118,15 @@ class _InfoList(list):
         if self._dicts is None:
             self._load()
             c = self._cols
-            # plain Python lists first: per-element NumPy conversions would dominate at 65 536 envs
-            lists = [([not x for x in c[src].tolist()] if neg else c[src].tolist()) for _, src, neg in self._keys]
-            names = [k for k, _, _ in self._keys]
+            # plain Python lists first (per-element NumPy conversions would dominate at 65 536 envs), then one dict literal per env
             tl = ((c["truncated"] != 0) & (c["terminated"] == 0)).tolist()
-            ds = [dict(zip(names, vals)) for vals in zip(*lists)]
-            for d, t in zip(ds, tl):
-                d["TimeLimit.truncated"] = t
+            if self._keys is MarlonVecEnv._INFO_KEYS:
+                ds = [{"invalid_action": iv, "cyber_step_executed": not iv, "network_availability": av, "step_count": sc, "TimeLimit.truncated": t}
+                      for iv, av, sc, t in zip(c["invalid_action"].tolist(), c["network_availability"].tolist(), c["step_count"].tolist(), tl)]
+            else:
+                lists = [([not x for x in c[src].tolist()] if neg else c[src].tolist()) for _, src, neg in self._keys]
+                names = [k for k, _, _ in self._keys]
+                ds = [dict(zip(names, vals), **{"TimeLimit.truncated": t}) for vals, t in zip(zip(*lists), tl)]
             for i in self._ended.tolist():
                 self._finish(ds[i], i)
             for i, d in self._some.items():                # dicts handed out (and possibly edited) before the bulk build stay the ones in the list

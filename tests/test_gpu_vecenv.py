@@ -392,3 +392,83 @@ def test_wrapper_step_with_the_staged_hot_image_equals_default(monkeypatch):
         for k in default.terminal_observation:
             assert torch.equal(default.terminal_observation[k], staged.terminal_observation[k]), f"step {t}: terminal observation {k}"
     default.close(); staged.close()
+
+
+@pytest.mark.parametrize("case", ["chain10_discrete", "toyctf_defender_multidiscrete", "chain4_discrete_graph", "toyctf_learned_defender"])
+def test_one_launch_wrapper_step_equals_three_launches(case, monkeypatch):
+    """mcbs_attacker_wrapper_step for small topologies without mask fields is ONE launch (mcbs_wrapper_fused.hip: decode, attacker's
+    action, observation assembled in LDS before the defender's turn, defender / goals, bookkeeping, auto-reset, observation streamed
+    out by the wavefront); MCBS_NO_FUSED_WRAPPER=1 keeps round 2's three launches.  Both wrappers take the same masked-random actions
+    (intercepted ones included) through episode ends: every output, the observation and terminal observation, mcbs_mask_logits (the
+    per-env digests) at every step and the engines' canonical state at intervals must agree.  Row shapes cover whole-vector rows
+    (Chain-10 @12/12), rows that are not (Chain-4 @6/6: 6 privilege dwords), the in-env and the learned defender, hipGraph replay.
+    attack_wrapper.py:255-372, action_masking.py:112-142, env.py:1153 vs 1156-1158."""
+    import torch
+    from marlon_amd import cyberbattle_env as ce
+    from marlon_amd.samples import chainpattern, toy_ctf
+    from marlon_amd.wrappers import AttackerVecEnv
+    from tests.test_gpu_parity import _compare_states
+    E = 1000                                                   # the last wavefront is partly empty
+    if case == "chain10_discrete":
+        env0, kw = chainpattern.new_environment(10), dict(maximum_node_count=12, maximum_total_credentials=12, discrete=True, max_timesteps=40)
+    elif case == "toyctf_defender_multidiscrete":
+        env0, kw = toy_ctf.new_environment(), dict(maximum_node_count=12, maximum_total_credentials=10, discrete=False, max_timesteps=35,
+                                                    attacker_goal=ce.AttackerGoal(own_atleast=6, own_atleast_percent=1.0),
+                                                    defender_constraint=ce.DefenderConstraint(0.8),
+                                                    defender_agent=ce.ScanAndReimageCompromisedMachines(0.6, 2, 5), seed=31)
+    elif case == "chain4_discrete_graph":
+        env0, kw = chainpattern.new_environment(4), dict(maximum_node_count=6, maximum_total_credentials=6, discrete=True, max_timesteps=25, use_graph=True)
+    else:
+        env0, kw = toy_ctf.new_environment(), dict(maximum_node_count=12, maximum_total_credentials=10, discrete=True, max_timesteps=30, learned_defender=True)
+    ref = AttackerVecEnv(env0, E, **{**kw, "use_graph": False})                         # masks materialised: the policy's masks come from here
+    fused = AttackerVecEnv(env0, E, materialize_masks=False, **kw)
+    monkeypatch.setenv("MCBS_NO_FUSED_WRAPPER", "1")
+    three = AttackerVecEnv(env0, E, materialize_masks=False, **kw)
+    monkeypatch.delenv("MCBS_NO_FUSED_WRAPPER")
+    dev = ref.engine.device
+    g = torch.Generator(device=dev).manual_seed(5)
+    ended = 0
+    for t in range(90):
+        m = ref.action_masks()
+        scores = torch.rand(m.shape, generator=g, device=dev)
+        a = torch.where(m, scores, torch.full_like(scores, -1.0)).argmax(dim=1)
+        if t % 7 == 3:
+            a[::9] = ref.discrete_n - 1                         # undiscovered node indices: intercepted, the env keeps its observation
+        if not kw["discrete"]:                                   # the same action as a MultiDiscrete(10) row (attack_wrapper.py:206-227)
+            N, Cm = kw["maximum_node_count"], kw["maximum_total_credentials"]
+            M, ML = ref._mask_split[0], ref._mask_split[1]
+            L, R, P = ML // N, (ref.discrete_n - M - ML) // (N * N), M // (N * N * Cm)
+            md = torch.zeros((E, 10), dtype=torch.int64, device=dev)
+            is_c, is_l = a < M, (a >= M) & (a < M + ML)
+            is_r = ~is_c & ~is_l
+            md[:, 0] = torch.where(is_c, 2, torch.where(is_l, 0, 1))
+            rel = torch.where(is_c, a, torch.where(is_l, a - M, a - M - ML))
+            md[:, 1] = torch.where(is_l, rel // L, 0); md[:, 2] = torch.where(is_l, rel % L, 0)
+            md[:, 3] = torch.where(is_r, rel // (N * R), 0); md[:, 4] = torch.where(is_r, (rel // R) % N, 0); md[:, 5] = torch.where(is_r, rel % R, 0)
+            md[:, 6] = torch.where(is_c, rel // (N * P * Cm), 0); md[:, 7] = torch.where(is_c, (rel // (P * Cm)) % N, 0)
+            md[:, 8] = torch.where(is_c, (rel // Cm) % P, 0); md[:, 9] = torch.where(is_c, rel % Cm, 0)
+            a = md
+        outs = [env.step(a.clone()) for env in (fused, three)]
+        r_ref = ref.step(a)                                      # the mask-writing wrapper advances with the same actions
+        (o1, r1, te1, tr1, i1), (o2, r2, te2, tr2, i2) = outs
+        ctx = f"{case} step {t}"
+        assert torch.equal(r1, r2) and torch.equal(te1, te2) and torch.equal(tr1, tr2), ctx + " rewards / flags"
+        assert torch.equal(r1, r_ref[1]) and torch.equal(te1, r_ref[2]) and torch.equal(tr1, r_ref[3]), ctx + " vs the mask-writing wrapper"
+        for k in i1:
+            assert torch.equal(i1[k], i2[k]), f"{ctx} info {k}"
+        for k in o1:
+            assert torch.equal(o1[k], o2[k]), f"{ctx} observation {k}"
+            assert torch.equal(o1[k], r_ref[0][k]), f"{ctx} observation {k} vs the mask-writing wrapper"
+        for k, x in fused.terminal_observation.items():
+            assert torch.equal(x, three.terminal_observation[k]), f"{ctx} terminal observation {k}"
+        for k in ("timesteps", "valid_action_count", "invalid_action_count", "episode_returns", "last_cyber_reward", "has_cyber_reward"):
+            assert torch.equal(getattr(fused, k), getattr(three, k)), f"{ctx} wrapper counter {k}"
+        assert torch.equal(fused._rows, three._rows), ctx + " decoded rows"
+        logits = torch.rand((E, fused.discrete_n), generator=g, device=dev)
+        assert torch.equal(fused.mask_logits(logits.clone(), -1.0), three.mask_logits(logits.clone(), -1.0)), ctx + " mask_logits (digests)"
+        ended += int((te1 | tr1).sum())
+        if t % 30 == 29:
+            _compare_states(fused.engine.get_state(), three.engine.get_state(), ctx)
+    assert ended > E // 2
+    for env in (ref, fused, three):
+        env.close()
