@@ -460,6 +460,10 @@ int  mcbs_attacker_wrapper_step(mcbs_batch*, const int64_t* multidiscrete, const
                                 const mcbs_row_copies* keep, const mcbs_row_copies* fresh, void* stream);
 int  mcbs_attacker_wrapper_finish(mcbs_batch*, const mcbs_wrapper_buffers* w, float invalid_action_reward_modifier, int32_t max_timesteps,
                                   int32_t auto_reset, const mcbs_row_copies* keep, const mcbs_row_copies* fresh, void* stream);
+/* How many kernel launches one mcbs_attacker_wrapper_step of this batch takes: 1 for small topologies (packed batch, at most 16 nodes and
+ * cached credentials) when no mask field is requested (with_masks == 0) — the whole step, observation included, is then ONE launch
+ * (marlon_amd/csrc/mcbs_wrapper_fused.hip) and replaying it from a hipGraph would only add the graph's own launch cost —, else 3. */
+int32_t mcbs_attacker_wrapper_step_launches(const mcbs_batch*, int32_t with_masks);
 
 /* The reward shaping of marlon's DefenderEnvWrapper.step (defend_wrapper.py:228-282) around mcbs_defender_step, for every env in one
  * launch and in the wrapper's own order of double-precision operations: invalid-action penalty, minus the attacker's last environment

@@ -958,6 +958,17 @@ static void launch_decode_step1_nw(mcbs_batch* b, const StepIO& io, const int64_
     else launch_decode_step1_v<WT, MCBS_DEFENDER_NONE>(b, io, md, discrete, invalid, st);
 }
 
+static bool fused_wrapper_batch_ok(const mcbs_batch* b) {
+    return !(b->no_fused_wrapper || b->lds_topo || b->no_fused_masks || !b->S.packed || !b->C.init_image_ok || b->S.N > 16u ||
+             b->cfg.maximum_node_count > 16u || b->cfg.maximum_total_credentials > 16u || b->topo->H()->n_triples > 15u ||
+             b->cfg.defender_kind == MCBS_DEFENDER_RANDOM_EVENTS);
+}
+
+extern "C" int32_t mcbs_attacker_wrapper_step_launches(const mcbs_batch* b, int32_t with_masks) {
+    if (!b) return 0;
+    return (!with_masks && fused_wrapper_batch_ok(b)) ? 1 : 3;
+}
+
 // The whole wrapper step in ONE launch (mcbs_wrapper_fused.hip) when the batch and the request fit it: packed batch whose reset image is
 // held in the config, at most 16 nodes / cached credentials, no mask field, observation rows of whole 16-byte vectors, every requested
 // field paired with its terminal array and its reset row (auto_reset).  Returns 1 when it launched, 0 when the caller should run the
@@ -967,9 +978,7 @@ static int try_fused_wrapper_step(mcbs_batch* b, const int64_t* multidiscrete, c
                                   const mcbs_row_copies* keep, const mcbs_row_copies* fresh, hipStream_t st) {
     const mcbs_topo_header* h = b->topo->H();
     const uint32_t Nm = b->cfg.maximum_node_count, Cm = b->cfg.maximum_total_credentials, K = b->cfg.maximum_discoverable_credentials_per_action;
-    if (b->no_fused_wrapper || b->lds_topo || b->no_fused_masks || !b->S.packed || !b->C.init_image_ok || b->S.N > 16u || Nm > 16u || Cm > 16u ||
-        h->n_triples > 15u || b->cfg.defender_kind == MCBS_DEFENDER_RANDOM_EVENTS || o->mask_local || o->mask_remote || o->mask_connect || o->mask_discrete)
-        return 0;
+    if (!fused_wrapper_batch_ok(b) || o->mask_local || o->mask_remote || o->mask_connect || o->mask_discrete) return 0;
     const uint32_t NP = b->C.n_props;
     FusedArgs A{};
     A.w = *w; A.modifier = modifier; A.max_timesteps = max_timesteps; A.auto_reset = auto_reset;

@@ -39,7 +39,8 @@ namespace mcbs {
 constexpr uint32_t FUSED_FIELDS = 5;          // 0 scalars [7], 1 leaked_credentials [K, 4], 2 credential_cache_matrix [Cmax, 2], 3 properties [Nmax, NP], 4 privilege [Nmax]
 constexpr uint32_t FUSED_FRESH_DWORDS = 1024; // LDS room for one reset observation
 constexpr uint32_t FUSED_THREADS = 256;        // one workgroup = 64 envs: the first wavefront steps them (lane = env), all four stream the observation
-constexpr uint32_t FUSED_STAGE_DWORDS = 29;   // per env; odd, so that the lane-per-env writes fall into 29 i mod 32: all banks
+constexpr uint32_t FUSED_STAGE_DWORDS = 37;   // per env; odd, so that lane-per-env accesses fall into 37 i mod 32: all banks
+constexpr uint32_t FUSED_RAW_DWORDS = 33;     // per env: what the stepping lane hands over (list heads, rows, sets); odd as well
 
 struct FusedArgs {                             // kernel argument, by value (the per-step output pointers change from step to step)
     mcbs_wrapper_buffers w;
@@ -62,17 +63,27 @@ struct FusedArgs {                             // kernel argument, by value (the
     uint32_t n_triples, pad;
 };
 
-struct FusedStage {                            // view of one env's 29 dwords of LDS
+struct FusedStage {                            // view of one env's 37 dwords of LDS: what the streaming loops read
     uint32_t* p;
-    // [0..16] properties of the node at discovery index j (17th: zero), [17] privilege, 2 bits per discovery index,
-    // [18..25] (node index | port << 8) of cached credential r as u16, [26] flags word of the step, [27] n_disc | n_creds << 8 | live << 16 |
-    // blank << 17 | ended << 18 | fresh << 19, [28] owned-source bits by discovery index
+    // [0..16] properties of the node at discovery index j (17th: zero), [17..20] privilege of the node at discovery index j, one byte each,
+    // [21..28] (node index | port << 8) of cached credential r as u16, [29] flags word of the step, [30] n_disc | n_creds << 8 | live << 16 |
+    // blank << 17 | ended << 18, [31] owned-source bits by discovery index, [32..35] discovery index of node n, one byte each
     __device__ __forceinline__ uint32_t& props(uint32_t j) const { return p[j]; }
-    __device__ __forceinline__ uint32_t& priv() const { return p[17]; }
-    __device__ __forceinline__ uint16_t* cred() const { return reinterpret_cast<uint16_t*>(p + 18); }
-    __device__ __forceinline__ uint32_t& flags() const { return p[26]; }
-    __device__ __forceinline__ uint32_t& meta() const { return p[27]; }
-    __device__ __forceinline__ uint32_t& own() const { return p[28]; }
+    __device__ __forceinline__ uint8_t* privb() const { return reinterpret_cast<uint8_t*>(p + 17); }
+    __device__ __forceinline__ uint32_t priv4(uint32_t r) const { return p[17 + r]; }
+    __device__ __forceinline__ uint16_t* cred() const { return reinterpret_cast<uint16_t*>(p + 21); }
+    __device__ __forceinline__ uint32_t& flags() const { return p[29]; }
+    __device__ __forceinline__ uint32_t& meta() const { return p[30]; }
+    __device__ __forceinline__ uint32_t& own() const { return p[31]; }
+    __device__ __forceinline__ uint8_t* ext_of() const { return reinterpret_cast<uint8_t*>(p + 32); }
+};
+struct FusedRaw {                              // view of one env's 33 dwords of LDS: written by the stepping lane between the attacker's action and the defender's turn
+    uint32_t* p;
+    // [0..3] discovery order (16 node ids), [4..11] credential cache (16 triple ids, u16), [12..27] the sixteen 4-byte node rows (target's as the
+    // attacker left it), [28] agent-installed | privilege bit 0 << 16, [29] privilege bit 1
+    __device__ __forceinline__ const uint8_t* disc() const { return reinterpret_cast<const uint8_t*>(p); }
+    __device__ __forceinline__ const uint16_t* cache() const { return reinterpret_cast<const uint16_t*>(p + 4); }
+    __device__ __forceinline__ uint32_t row(uint32_t n) const { return p[12 + n]; }
 };
 constexpr uint32_t FM_LIVE = 1u << 16, FM_BLANK = 1u << 17, FM_ENDED = 1u << 18;
 
@@ -94,10 +105,11 @@ struct FusedHook {
     int32_t row[5];
     bool invalid;
 
-    __device__ __forceinline__ FusedStage stage(uint32_t env_in_wave) const { return FusedStage{lds + env_in_wave * FUSED_STAGE_DWORDS}; }
-    __device__ __forceinline__ uint32_t* fresh_lds() const { return lds + 64u * FUSED_STAGE_DWORDS; }
-    __device__ __forceinline__ uint32_t* triple_lds() const { return lds + 64u * FUSED_STAGE_DWORDS + FUSED_FRESH_DWORDS; }
-    __device__ __forceinline__ uint32_t* rdig_lds() const { return lds + 64u * FUSED_STAGE_DWORDS + FUSED_FRESH_DWORDS + 32u; }
+    __device__ __forceinline__ FusedStage stage(uint32_t env_in_wg) const { return FusedStage{lds + env_in_wg * FUSED_STAGE_DWORDS}; }
+    __device__ __forceinline__ FusedRaw raw(uint32_t env_in_wg) const { return FusedRaw{lds + 64u * FUSED_STAGE_DWORDS + env_in_wg * FUSED_RAW_DWORDS}; }
+    __device__ __forceinline__ uint32_t* fresh_lds() const { return lds + 64u * (FUSED_STAGE_DWORDS + FUSED_RAW_DWORDS); }
+    __device__ __forceinline__ uint32_t* triple_lds() const { return fresh_lds() + FUSED_FRESH_DWORDS; }
+    __device__ __forceinline__ uint32_t* rdig_lds() const { return fresh_lds() + FUSED_FRESH_DWORDS + 32u; }
 
     __device__ __forceinline__ void load_action(uint32_t ec) {
         const int64_t* v = A.md ? A.md + (size_t)ec * 10 : A.discrete + ec;      // (one load of p0 for both encodings: two stores of loaded
@@ -176,41 +188,62 @@ struct FusedHook {
         a4 = (uint32_t)row[4];
     }
 
-    // What the env's observation is made of, from the step's registers into this lane's LDS record (obs_tiny_kernel's staging, lane = env)
+    // Between the attacker's action and the defender's turn: the stepping lane hands what its env's observation is made of to the workgroup
+    // — list heads, node rows, the three sets — as it holds them in registers (nine 16-byte LDS writes), plus flags and counts.
     template <class LaneT>
     __device__ __forceinline__ void stage_obs(const DevState& S, const StepCfg& C, const LaneT& ln, uint32_t flags, bool not_skipped) {
 #if defined(FUSED_EXP) && FUSED_EXP == 3
         return;
 #endif
+        const FusedRaw rw = raw(lane);
+        rw.p[0] = ln.rec_dh.x; rw.p[1] = ln.rec_dh.y; rw.p[2] = ln.rec_dh.z; rw.p[3] = ln.rec_dh.w;
+        rw.p[4] = ln.rec_c0.x; rw.p[5] = ln.rec_c0.y; rw.p[6] = ln.rec_c0.z; rw.p[7] = ln.rec_c0.w;
+        rw.p[8] = ln.rec_c1.x; rw.p[9] = ln.rec_c1.y; rw.p[10] = ln.rec_c1.z; rw.p[11] = ln.rec_c1.w;
+        rw.p[12] = ln.prw0.x; rw.p[13] = ln.prw0.y; rw.p[14] = ln.prw0.z; rw.p[15] = ln.prw0.w;
+        rw.p[16] = ln.prw1.x; rw.p[17] = ln.prw1.y; rw.p[18] = ln.prw1.z; rw.p[19] = ln.prw1.w;
+        rw.p[20] = ln.prw2.x; rw.p[21] = ln.prw2.y; rw.p[22] = ln.prw2.z; rw.p[23] = ln.prw2.w;
+        rw.p[24] = ln.prw3.x; rw.p[25] = ln.prw3.y; rw.p[26] = ln.prw3.z; rw.p[27] = ln.prw3.w;
+        rw.p[12 + (ln.ptgt & 15u)] = ln.pword;              // the target's row as the attacker left it (same lane, program order)
+        rw.p[28] = ((uint32_t)ln.m[M_INST][0] & 0xFFFFu) | ((uint32_t)ln.m[M_PLO][0] << 16);
+        rw.p[29] = (uint32_t)ln.m[M_PHI][0];
         const FusedStage st = stage(lane);
-        const uint32_t n_disc = ln.n_disc, n_creds = ln.n_creds;
-        const uint32_t inst = (uint32_t)ln.m[M_INST][0], plo = (uint32_t)ln.m[M_PLO][0], phi = (uint32_t)ln.m[M_PHI][0];
-        const uint32_t pmask = (1u << S.tiny_p) - 1u;
-        uint64_t ext_of = 0ull;            // discovery index of node n, 4 bits each
-        uint32_t priv = 0u, own = 0u;
-        for (uint32_t j = 0; j < S.N; ++j) {                     // (uniform bound; entries beyond n_disc are zero)
-            const uint32_t n = byte_of(ln.rec_dh, j) & 15u;
-            const uint32_t word = n == ln.ptgt ? ln.pword : dword_of(ln.prw0, ln.prw1, ln.prw2, ln.prw3, n);
-            const bool on = j < n_disc;
-            st.props(j) = on ? (word & pmask) : 0u;
-            priv |= on ? ((((plo >> n) & 1u) | (((phi >> n) & 1u) << 1)) << (2u * j)) : 0u;
-            own |= (on ? ((inst >> n) & 1u) : 0u) << j;
-            ext_of |= on ? ((uint64_t)j << (4u * n)) : 0ull;
-        }
-        for (uint32_t j = S.N; j < 17u; ++j) st.props(j) = 0u;
-        st.priv() = priv;
-        const uint32_t* tr = triple_lds();
-        uint16_t* cr = st.cred();
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // (the triple table was written by lanes 0..15 of this wavefront)
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (uint32_t r = 0; r < A.n_triples; ++r) {                  // (uniform bound; entries beyond n_creds are never read)
-            const uint32_t t = tr[half_of(ln.rec_c0, ln.rec_c1, r) & 15u];          // node | port << 16
-            cr[r] = (uint16_t)(((uint32_t)(ext_of >> (4u * (t & 15u))) & 15u) | ((t >> 16) << 8));
-        }
         const bool blank = (flags & F_OOB) != 0;
         st.flags() = flags;
-        st.meta() = n_disc | (n_creds << 8) | (not_skipped ? FM_LIVE : 0u) | (blank ? FM_BLANK : 0u);
-        st.own() = blank ? 0u : own;
+        st.meta() = ln.n_disc | (ln.n_creds << 8) | (not_skipped ? FM_LIVE : 0u) | (blank ? FM_BLANK : 0u);
+    }
+
+    // ... and the whole workgroup (thread `lane` of FUSED_THREADS) turns the 64 hand-overs into the records the streaming loops read:
+    // pass A, one (env, discovery index) per thread and iteration; pass B, one (env, cached credential) — obs_tiny_kernel's staging, spread
+    // over four wavefronts instead of serialised behind the stepping lane (2.7 of its 9 us).
+    __device__ __forceinline__ void convert_nodes(const DevState& S) {
+        const uint32_t pmask = (1u << S.tiny_p) - 1u;
+        for (uint32_t item = lane; item < 64u * 16u; item += FUSED_THREADS) {
+            const uint32_t env = item >> 4, j = item & 15u;
+            const FusedRaw rw = raw(env);
+            const FusedStage st = stage(env);
+            const uint32_t meta = st.meta(), n_disc = meta & 0xFFu;
+            const uint32_t n = rw.disc()[j] & 15u;
+            const bool on = j < n_disc;
+            const uint32_t sets = rw.p[28], phi = rw.p[29];
+            st.props(j) = on ? (rw.row(n) & pmask) : 0u;
+            st.privb()[j] = (on && !(meta & FM_BLANK)) ? (uint8_t)((((sets >> 16) >> n) & 1u) | (((phi >> n) & 1u) << 1)) : (uint8_t)0;
+            if (on) st.ext_of()[n] = (uint8_t)j;
+            const uint64_t owned = __ballot(on && ((sets >> n) & 1u));          // four envs per wavefront and iteration, 16 bits each
+            if (j == 0u) {
+                st.props(16) = 0u;
+                st.own() = (meta & FM_BLANK) ? 0u : (uint32_t)(owned >> ((lane & 48u))) & 0xFFFFu;
+            }
+        }
+    }
+    __device__ __forceinline__ void convert_creds() {
+        const uint32_t* tr = triple_lds();
+        for (uint32_t item = lane; item < 64u * 16u; item += FUSED_THREADS) {
+            const uint32_t env = item >> 4, r = item & 15u;
+            const FusedRaw rw = raw(env);
+            const FusedStage st = stage(env);
+            const uint32_t t = tr[rw.cache()[r] & 15u];                          // node | port << 16 (entries beyond n_creds are never read)
+            st.cred()[r] = (uint16_t)((uint32_t)st.ext_of()[t & 15u] | ((t >> 16) << 8));
+        }
     }
 
     // After the step's own stores: the wrapper's bookkeeping (wrapper_finish_body, word for word), the re-initialisation of an env that
@@ -277,7 +310,7 @@ struct FusedHook {
             const uint32_t i = fdiv(idx, A.dNP), p = idx - i * A.NP;
             return (st.props(i) >> p) & 1u;
         }
-        if (f == 4) return (!blank && idx < n_disc) ? (st.priv() >> (2u * idx)) & 3u : 0u;
+        if (f == 4) return (uint32_t)st.privb()[idx & 15u];                       // (zero beyond n_disc and for a blank observation: convert_nodes)
         if (f == 2) {
             const uint32_t r = idx >> 1, c = st.cred()[r & 15u];
             return (!blank && r < n_creds) ? ((idx & 1u) ? c >> 8 : c & 0xFFu) : 0u;
@@ -320,11 +353,9 @@ struct FusedHook {
                 const bool blank = meta & FM_BLANK;
                 uint4 v;
                 if (f == 3) v = props4(st, r, n_disc, blank);
-                else if (f == 4) {                                    // privilege of the nodes at discovery indices 4r .. 4r + 3
-                    const uint32_t pv = blank ? 0u : st.priv() >> (8u * r);
-                    const uint32_t j = 4u * r;
-                    v = make_uint4(j < n_disc ? pv & 3u : 0u, j + 1u < n_disc ? (pv >> 2) & 3u : 0u, j + 2u < n_disc ? (pv >> 4) & 3u : 0u,
-                                   j + 3u < n_disc ? (pv >> 6) & 3u : 0u);
+                else if (f == 4) {                                    // privilege of the nodes at discovery indices 4r .. 4r + 3: one byte each
+                    const uint32_t pv = st.priv4(r & 3u);
+                    v = make_uint4(pv & 0xFFu, (pv >> 8) & 0xFFu, (pv >> 16) & 0xFFu, pv >> 24);
                 } else if (f == 2) {                                  // cache entries 2r, 2r + 1: (node index, port)
                     const uint16_t* cr = st.cred();
                     const uint32_t c0 = cr[(2u * r) & 15u], c1 = cr[(2u * r + 1u) & 15u];
@@ -396,7 +427,7 @@ struct FusedHook {
 
 template <int DEFK>
 __global__ __launch_bounds__(FUSED_THREADS) void wrapper_fused_kernel(DevState S, Topo T, const StepCfg* __restrict__ Cp, StepIO io, FusedArgs A) {
-    __shared__ uint32_t lds[64u * FUSED_STAGE_DWORDS + FUSED_FRESH_DWORDS + 32u + 16u];
+    __shared__ uint32_t lds[64u * (FUSED_STAGE_DWORDS + FUSED_RAW_DWORDS) + FUSED_FRESH_DWORDS + 32u + 16u];
     const uint32_t tid = threadIdx.x;
     FusedHook hook{A, lds, tid, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.0, {0, 0, 0, 0, 0}, false};
     // The first wavefront advances the workgroup's 64 envs (lane = env: the headline kernel's code with the hooks above) and leaves their
@@ -404,11 +435,15 @@ __global__ __launch_bounds__(FUSED_THREADS) void wrapper_fused_kernel(DevState S
     // with one wavefront per SIMD every LDS round trip of the streaming loops was exposed (30 us per launch); four hide each other's.
     if (tid < 64u) step_body<0, 0, false, DEFK, false>(S, T, Cp, io, RollArgs{}, hook);
     else hook.fill_reset_rows(tid - 64u, FUSED_THREADS - 64u);
-    // LDS-only barrier: the records are complete (lgkmcnt(0)), nobody waits for the global stores in flight (vmcnt untouched)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // LDS-only barriers: the records are complete (lgkmcnt(0)), nobody waits for the global stores in flight (vmcnt untouched)
+#define MCBS_LDS_BARRIER() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_s_waitcnt(0xC07F); \
+                                __builtin_amdgcn_s_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+    MCBS_LDS_BARRIER();
+    hook.convert_nodes(S);
+    MCBS_LDS_BARRIER();
+    hook.convert_creds();
+    MCBS_LDS_BARRIER();
+#undef MCBS_LDS_BARRIER
 #if !defined(FUSED_EXP) || (FUSED_EXP != 1 && FUSED_EXP != 3)
     hook.stream(S, blockIdx.x * 64u);
 #endif

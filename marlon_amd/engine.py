@@ -24,6 +24,7 @@ EXPORTS = [
     "mcbs_batch_destroy", "mcbs_reset", "mcbs_rewind", "mcbs_step", "mcbs_step_observe", "mcbs_observe", "mcbs_observe_masked", "mcbs_action_mask", "mcbs_step_info",
     "mcbs_step_many", "mcbs_rollout_random", "mcbs_attacker_wrapper_post", "mcbs_attacker_wrapper_clear", "mcbs_defender_wrapper_post", "mcbs_sample_actions", "mcbs_decode_attacker_actions", "mcbs_defender_step", "mcbs_defender_observe", "mcbs_set_draw_tape", "mcbs_state_record_bytes", "mcbs_get_state", "mcbs_set_state",
     "mcbs_timing_enable", "mcbs_timing_read", "mcbs_mask_logits", "mcbs_discrete_action_count", "mcbs_copy_rows_masked", "mcbs_attacker_wrapper_finish", "mcbs_attacker_wrapper_step",
+    "mcbs_attacker_wrapper_step_launches",
 ]
 
 _lib = None
@@ -84,6 +85,8 @@ def load_library(path: Optional[str] = None):
     lib.mcbs_attacker_wrapper_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int32,
                                                C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.mcbs_attacker_wrapper_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.mcbs_attacker_wrapper_step_launches.restype = C.c_int32
+    lib.mcbs_attacker_wrapper_step_launches.argtypes = [C.c_void_p, C.c_int32]
     lib.mcbs_timing_enable.argtypes = [C.c_void_p, C.c_int32]
     lib.mcbs_timing_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     for name in EXPORTS:
@@ -300,6 +303,10 @@ class BatchEngine:
                                                              C.byref(self._info_struct), C.byref(obs_struct), C.byref(bufs), float(modifier),
                                                              int(max_timesteps), int(bool(auto_reset)), C.byref(keep), C.byref(fresh), self._stream()),
                "mcbs_attacker_wrapper_step")
+
+    def wrapper_step_launches(self, with_masks: bool) -> int:
+        """Kernel launches per mcbs_attacker_wrapper_step of this batch (1: the whole wrapper step is one launch; 3 otherwise)."""
+        return int(self.lib.mcbs_attacker_wrapper_step_launches(self._h, int(bool(with_masks))))
 
     def obs_struct(self, obs: dict):
         """Argument block (_abi.ObsBuffers) for wrapper_step, built once for a set of persistent observation tensors."""
