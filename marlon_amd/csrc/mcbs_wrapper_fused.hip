@@ -192,9 +192,6 @@ struct FusedHook {
     // — list heads, node rows, the three sets — as it holds them in registers (nine 16-byte LDS writes), plus flags and counts.
     template <class LaneT>
     __device__ __forceinline__ void stage_obs(const DevState& S, const StepCfg& C, const LaneT& ln, uint32_t flags, bool not_skipped) {
-#if defined(FUSED_EXP) && FUSED_EXP == 3
-        return;
-#endif
         const FusedRaw rw = raw(lane);
         rw.p[0] = ln.rec_dh.x; rw.p[1] = ln.rec_dh.y; rw.p[2] = ln.rec_dh.z; rw.p[3] = ln.rec_dh.w;
         rw.p[4] = ln.rec_c0.x; rw.p[5] = ln.rec_c0.y; rw.p[6] = ln.rec_c0.z; rw.p[7] = ln.rec_c0.w;
@@ -376,10 +373,6 @@ struct FusedHook {
     __device__ __forceinline__ void stream(const DevState& S, uint32_t e0) {
         const uint32_t n_env = S.E - e0 < 64u ? S.E - e0 : 64u;       // envs of this wavefront
         const uint32_t* fr = fresh_lds();
-#if defined(FUSED_EXP) && FUSED_EXP == 2
-        stream_field<3>(e0, n_env);
-        return;
-#endif
         stream_field<1>(e0, n_env); stream_field<2>(e0, n_env); stream_field<3>(e0, n_env); stream_field<4>(e0, n_env);
         // ---- field 0: seven scalars per env, dword by dword ----
         if (A.obs[0]) {
@@ -444,9 +437,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void wrapper_fused_kernel(DevState S
     hook.convert_creds();
     MCBS_LDS_BARRIER();
 #undef MCBS_LDS_BARRIER
-#if !defined(FUSED_EXP) || (FUSED_EXP != 1 && FUSED_EXP != 3)
     hook.stream(S, blockIdx.x * 64u);
-#endif
 }
 
 } // namespace mcbs
