@@ -79,6 +79,7 @@ struct mcbs_batch {
     uint32_t* ere_lists_dev = nullptr;
     // developer switches, read ONCE at batch creation (getenv on every launch costs more than the launch itself)
     bool lds_topo = false, no_fused_masks = false, slow_masks = false, no_row_masks = false;
+    bool no_block_masks = false;    // MCBS_NO_BLOCK_MASKS=1: round 2's fused mask writers (rows switched on / off per chunk)
     bool no_fused_wrapper = false;  // MCBS_NO_FUSED_WRAPPER=1: mcbs_attacker_wrapper_step keeps its three launches (tests step both)
     bool coop = false;              // mcbs_step runs the G-lanes-per-env kernel (mcbs_step_coop.hip): more than 64 nodes, sets of 2 or 4 words
     uint32_t step_block_override = 0;
@@ -325,7 +326,7 @@ extern "C" int mcbs_batch_create(const mcbs_topology* topo, const mcbs_batch_cfg
     b->cfg = *cfg;
     b->lds_topo = getenv("MCBS_LDS_TOPO") != nullptr; b->no_fused_masks = getenv("MCBS_NO_FUSED_MASKS") != nullptr;
     b->slow_masks = getenv("MCBS_SLOW_MASKS") != nullptr; b->no_row_masks = getenv("MCBS_NO_ROW_MASKS") != nullptr;
-    b->no_fused_wrapper = getenv("MCBS_NO_FUSED_WRAPPER") != nullptr;
+    b->no_fused_wrapper = getenv("MCBS_NO_FUSED_WRAPPER") != nullptr; b->no_block_masks = getenv("MCBS_NO_BLOCK_MASKS") != nullptr;
     if (const char* ov = getenv("MCBS_STEP_BLOCK")) b->step_block_override = (uint32_t)atoi(ov);   // experiments only (64, 128 or 256)
     const uint32_t E = cfg->n_envs, N = h->n_nodes;
     DevState& S = b->S;
@@ -745,13 +746,31 @@ static int launch_obs_inner(mcbs_batch* b, const mcbs_obs_buffers* o, hipStream_
             O.fuse_connect = 3; O.conn_pc = (uint32_t)(RL / g16);                                                            // 16-byte chunks, any RL >= 16
         } else if (dwords_ok && reinterpret_cast<uintptr_t>(o->mask_connect) % 4 == 0) O.fuse_connect = 2;                  // dwords, any RL
     }
+    // per-source blocks (mcbs_obs.hip stream_blocks): where round 2 switched row bytes on and off per chunk (connect rows that are not a
+    // multiple of 16 bytes; the remote mask as dwords), a chunk is now one LDS read of a block variant.  Needs dword-sized blocks of at
+    // least one chunk and whole-chunk masks; MCBS_NO_BLOCK_MASKS=1: round 2's writers
+    uint32_t blk_bytes = 0;
+    const size_t BLc = (size_t)O.Nmax * RL, BLr = (size_t)O.Nmax * b->C.R;
+    if (!b->no_block_masks) {
+        if (O.fuse_connect == 3 && BLc % 4 == 0 && BLc >= 16 && BLc <= 4064) { O.fuse_connect = 4; blk_bytes = (uint32_t)BLc; }
+        if (O.fuse_remote && BLr % 4 == 0 && BLr >= 16 && BLr <= 4064 && MR % 16 == 0 && reinterpret_cast<uintptr_t>(o->mask_remote) % 16 == 0) {
+            O.fuse_remote = 2;
+            if (BLr > blk_bytes) blk_bytes = (uint32_t)BLr;
+        }
+    }
+    O.fuse_discrete = dwords_ok && o->mask_discrete && ML % 4 == 0 && MR % 4 == 0 && b->C.L > 0 && b->C.R > 0 &&
+                      reinterpret_cast<uintptr_t>(o->mask_discrete) % 4 == 0;
+    O.disc_blocks = (!b->no_block_masks && O.fuse_discrete && RL % 16 != 0 && BLc % 4 == 0 && BLc >= 16 && BLc <= 4064) ? 1u : 0u;
+    if (O.disc_blocks && BLc > blk_bytes) blk_bytes = (uint32_t)BLc;
+    O.disc_remote_blocks = (!b->no_block_masks && O.fuse_discrete && BLr % 4 == 0 && BLr >= 16 && BLr <= 4064) ? 1u : 0u;
+    if (O.disc_remote_blocks && BLr > blk_bytes) blk_bytes = (uint32_t)BLr;
+    O.blk_region = blk_bytes ? ((blk_bytes + 16u + 15u) / 16u) * 4u : 0u;
+    O.dBLc = fast_div_host(BLc ? (uint32_t)BLc : 1u); O.dBLr = fast_div_host(BLr ? (uint32_t)BLr : 1u);
     O.nt_connect = (O.fuse_connect == 1 && M % 128 == 0 && reinterpret_cast<uintptr_t>(o->mask_connect) % 128 == 0) ? 1u : 0u;
     auto fdh = [](size_t d) { return fast_div_host(d ? (uint32_t)d : 1u); };
     O.dNP = fdh(b->C.n_props); O.dL = fdh(b->C.L); O.dR = fdh(b->C.R); O.dNm = fdh(O.Nmax); O.dRL = fdh(RL); O.dC = fdh(O.Cmax);
     O.dPC = fdh(O.conn_pc); O.dCPR = fdh(RL >> 4);
-    O.fuse_discrete = dwords_ok && o->mask_discrete && ML % 4 == 0 && MR % 4 == 0 && b->C.L > 0 && b->C.R > 0 &&
-                      reinterpret_cast<uintptr_t>(o->mask_discrete) % 4 == 0;
-    const uint32_t obs_shm = 4u * obs_stage_bytes(b->S.N, b->topo->H()->n_triples);
+    const uint32_t obs_shm = 4u * obs_stage_bytes(b->S.N, b->topo->H()->n_triples, O.blk_region);
     const bool no_masks = !o->mask_local && !o->mask_remote && !o->mask_connect && !o->mask_discrete;
     if (!env_mask && !masks_only && no_masks && b->S.NW == 1u && b->S.N <= 16u && O.Nmax <= 16u && O.Cmax <= 16u && b->topo->H()->n_triples <= 15u &&
         b->cfg.defender_kind != MCBS_DEFENDER_RANDOM_EVENTS && !b->no_fused_masks) {

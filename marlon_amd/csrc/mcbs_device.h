@@ -212,15 +212,20 @@ struct ObsIO {
     uint32_t masks_only;   // compute_action_mask: ignore the out-of-bound flag, write only mask fields
     // small action spaces (<= 256 (source, target) pairs): the per-env wavefront of obs_small_kernel also streams the two big
     // masks, so that one launch writes the whole observation and the digest never makes a round trip through memory
-    uint32_t fuse_remote;  // 1: mask_remote written by obs_small_kernel
+    uint32_t fuse_remote;  // mask_remote written by obs_small_kernel: 1 = dwords; 2 = 16-byte chunks of per-source blocks (mcbs_obs.hip stream_blocks)
     uint32_t fuse_connect; // mask_connect written by obs_small_kernel: 1 = 16-byte chunks, row length P*C a multiple of 16; 2 = dwords, any row
-                           // length; 3 = 16-byte chunks for row lengths that are NOT a multiple of 16 (ToyCtf: 70), pattern of one lcm period
+                           // length; 3 = 16-byte chunks for row lengths that are NOT a multiple of 16 (ToyCtf: 70), pattern of one lcm period;
+                           // 4 = 16-byte chunks of per-source blocks in four LDS variants (stream_blocks)
+    uint32_t disc_remote_blocks;  // 1: ... and so does its remote region
+    uint32_t disc_blocks;  // 1: the connect region of mask_discrete (row lengths that are not a multiple of 16) goes through per-source blocks too
+    uint32_t blk_region;   // dwords per block variant in LDS (the larger of the connect / remote blocks + 16 bytes, rounded up to 16 bytes); 0: unused
     uint32_t conn_pc;      // fuse_connect == 3: chunks per pattern period, lcm(P*C, 16) / 16
     uint32_t nt_connect;   // 1: the fused connect stream uses non-temporal stores (every env's mask is whole 128-byte lines)
     uint32_t fuse_discrete; // 1: mask_discrete (connect | local | remote per env, 4-byte granularity) written by obs_small_kernel
     // divisors of the observation's index arithmetic (a generic 32-bit division costs ~25 instructions per lane, and the per-env
     // routine had a score of them): properties per node, local / remote ids, Nmax, row length P*C, Cmax, pattern period, chunks per row
     FastDiv dNP, dL, dR, dNm, dRL, dC, dPC, dCPR;
+    FastDiv dBLc, dBLr;    // per-source block lengths: Nmax * P * Cmax (connect), Nmax * R (remote)
 };
 
 // Local-vulnerability mask of node n as the action mask sees it (env.py:653-659): static, except under ExternalRandomEvents where

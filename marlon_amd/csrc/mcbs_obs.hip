@@ -50,10 +50,11 @@ struct ObsStage {            // carved out of dynamic shared memory, sized for t
     uint8_t*  cred_node;     // [T]  node id of cached credential r
     uint8_t*  cred_port;     // [T]  port index of cached credential r
     uint8_t*  onb;           // [260] fused masks: row q = (source, target) is on
+    uint32_t* blk;           // [4 x blk_region dwords] per-source block of a fused mask in its four on / off variants (see stream_blocks)
 };
-__host__ __device__ inline uint32_t obs_stage_bytes(uint32_t n_nodes, uint32_t n_triples) {   // per wavefront, multiple of 16
+__host__ __device__ inline uint32_t obs_stage_bytes(uint32_t n_nodes, uint32_t n_triples, uint32_t blk_region = 0) {   // per wavefront, multiple of 16
     const uint32_t N = (n_nodes + 15u) & ~15u, T = (n_triples + 16u) & ~15u;
-    return 8u * N + 4u * N + 1040u + N + N + T + T + 272u;
+    return 8u * N + 4u * N + 1040u + N + N + T + T + 272u + 16u * blk_region;
 }
 __device__ __forceinline__ ObsStage obs_stage_at(uint8_t* base, uint32_t n_nodes, uint32_t n_triples) {
     const uint32_t N = (n_nodes + 15u) & ~15u, T = (n_triples + 16u) & ~15u;
@@ -65,7 +66,8 @@ __device__ __forceinline__ ObsStage obs_stage_at(uint8_t* base, uint32_t n_nodes
     s.priv = base; base += N;
     s.cred_node = base; base += T;
     s.cred_port = base; base += T;
-    s.onb = base;
+    s.onb = base; base += 272u;
+    s.blk = reinterpret_cast<uint32_t*>(base);
     return s;
 }
 
@@ -265,7 +267,48 @@ __device__ __forceinline__ void obs_env(const DevState& S, const Topo& T, const 
             }
         }
     };
-    if (O.fuse_remote) stream_remote_dwords(reinterpret_cast<uint32_t*>(O.mask_remote + (size_t)e * rows * C.R));
+    // PER-SOURCE BLOCKS.  connect[s][t][p][c] = owned(s) && t < n_disc && c < n_creds and remote[s][t][r] = owned(s) && t < n_disc: the
+    // Nm x RL (Nm x R) bytes of one source are the SAME block for every owned source and zeros for the others.  The block is built once per
+    // env in LDS in four variants — what a 16-byte chunk starting in source s's block reads depends only on (owned(s), owned(s + 1)):
+    // [0] zeros, [1] block ++ 16 zeros, [2] zeros ++ the block's first 16 bytes, [3] block ++ its first 16 bytes — so that a chunk is
+    // ONE address computation and one 16-byte LDS read, live or dead, straddling two sources or not (round 2 switched the bytes of the
+    // (at most two) ROWS a chunk touches on and off per chunk: ~50 instructions, and ToyCtf's observation was bound by instruction issue).
+    auto build_blocks = [&](uint32_t BL, uint32_t RG, auto&& dword_at) {     // dword_at(b): the block's four bytes at offset b (< BL, multiple of 4)
+        __builtin_amdgcn_wave_barrier();                   // (an earlier env's / field's blocks may still be in use by other lanes)
+        const uint32_t bw = BL >> 2;
+        for (uint32_t wd = lane; wd < bw + 4u; wd += 64u) {
+            const bool tail = wd >= bw;
+            const uint32_t w = dword_at(tail ? (wd - bw) * 4u : wd * 4u);
+            st.blk[wd] = 0u;
+            st.blk[RG + wd] = tail ? 0u : w;
+            st.blk[2u * RG + wd] = tail ? w : 0u;
+            st.blk[3u * RG + wd] = w;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+    };
+    auto stream_blocks = [&](uint4* out, uint32_t total, uint32_t BL, uint32_t RG, const FastDiv& dBL, uint32_t B0) {   // chunk c = mask bytes B0 + 16 c ..
+        const uint32_t srcs = blank ? 0u : (uint32_t)own_ext[0];          // bit s: the node at discovery index s is an owned source (Nm <= 16)
+        const uint32_t ds = fdiv(1024u, dBL), doff = 1024u - ds * BL;
+        uint32_t sidx = fdiv(B0 + lane * 16u, dBL), off = B0 + lane * 16u - sidx * BL;
+        for (uint32_t c = lane; c < total; c += 64u) {
+            const uint32_t* p = st.blk + ((srcs >> sidx) & 3u) * RG + (off >> 2);
+            out[c] = make_uint4(p[0], p[1], p[2], p[3]);
+            off += doff; sidx += ds;
+            if (off >= BL) { off -= BL; sidx += 1u; }
+        }
+    };
+    if (O.fuse_remote == 2u) {
+        const uint32_t R = C.R, BL = Nm * R;
+        build_blocks(BL, O.blk_region, [&](uint32_t b) -> uint32_t {
+            uint32_t w = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < 4u; ++i) w |= (uint32_t)(fdiv(b + i, O.dR) < n_disc) << (8u * i);
+            return blank ? 0u : w;
+        });
+        stream_blocks(reinterpret_cast<uint4*>(O.mask_remote + (size_t)e * rows * R), (rows * R) >> 4, BL, O.blk_region, O.dBLr, 0u);
+    }
+    if (O.fuse_remote == 1u) stream_remote_dwords(reinterpret_cast<uint32_t*>(O.mask_remote + (size_t)e * rows * C.R));
     // General form of the connect region, any row length RL (ToyCtf: 70 bytes), as dwords: the bytes of one "on" row sit in LDS
     // followed by its first four bytes again, so the dword at row offset r is two aligned LDS words shifted by r & 3; the bytes
     // that spill into the next row take that row's on/off.  (row, offset) advance incrementally by 256 bytes per iteration.
@@ -351,6 +394,23 @@ __device__ __forceinline__ void obs_env(const DevState& S, const Topo& T, const 
             if (pj >= PC) pj -= PC;
         }
     }
+    auto connect_block_dword = [&](uint32_t b) -> uint32_t {      // four bytes of one source's connect block [t][p][c] at offset b
+        const uint32_t Cc = O.Cmax, RL = C.P * Cc;
+        uint32_t t = fdiv(b, O.dRL), r = b - t * RL, c = r - fdiv(r, O.dC) * Cc, w = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 4u; ++i) {
+            w |= (uint32_t)(t < n_disc && c < n_creds) << (8u * i);
+            r += 1u; c += 1u;
+            if (c == Cc) c = 0u;
+            if (r == RL) { r = 0u; c = 0u; t += 1u; }
+        }
+        return blank ? 0u : w;
+    };
+    if (O.fuse_connect == 4u) {
+        const uint32_t RL = C.P * O.Cmax, BL = Nm * RL;
+        build_blocks(BL, O.blk_region, connect_block_dword);
+        stream_blocks(reinterpret_cast<uint4*>(O.mask_connect + (size_t)e * rows * RL), (rows * RL) >> 4, BL, O.blk_region, O.dBLc, 0u);
+    }
     if (O.fuse_connect == 2u) stream_connect_dwords(reinterpret_cast<uint32_t*>(O.mask_connect + (size_t)e * rows * C.P * O.Cmax));
     if (O.fuse_connect == 1u) {
         // connect[s][t][p][c] = on(s, t) && c < n_creds.  An "on" row is RL = P*C bytes of the pattern "n_creds ones, C - n_creds
@@ -402,6 +462,28 @@ __device__ __forceinline__ void obs_env(const DevState& S, const Topo& T, const 
             }
             return (uint32_t)row_on(fdiv(b - ML, O.dR));
         };
+        // the remote region of the flat mask ([M + ML, D): 4-byte aligned) as per-source blocks: whole 16-byte chunks from LDS, the few
+        // bytes before / after them as dwords
+        auto remote_region_blocks = [&]() {
+            int8_t* rb = base + M + ML;
+            const uint32_t h2 = (16u - (uint32_t)(reinterpret_cast<uintptr_t>(rb) & 15u)) & 15u, BLr = Nm * R;
+            build_blocks(BLr, O.blk_region, [&](uint32_t b) -> uint32_t {
+                uint32_t w = 0;
+#pragma unroll
+                for (uint32_t i = 0; i < 4u; ++i) w |= (uint32_t)(fdiv(b + i, O.dR) < n_disc) << (8u * i);
+                return blank ? 0u : w;
+            });
+            const uint32_t nch = (MR - h2) >> 4, t2 = h2 + (nch << 4);
+            if (lane * 4u < h2 || (lane >= 4u && lane < 8u && t2 + (lane - 4u) * 4u < MR)) {
+                const uint32_t b0 = lane < 4u ? lane * 4u : t2 + (lane - 4u) * 4u;
+                uint32_t v = 0;
+#pragma unroll
+                for (uint32_t b = 0; b < 4u; ++b) v |= byte_at(M + ML + b0 + b) << (8u * b);
+                *reinterpret_cast<uint32_t*>(rb + b0) = v;
+            }
+            stream_blocks(reinterpret_cast<uint4*>(rb + h2), nch, BLr, O.blk_region, O.dBLr, h2);
+        };
+        const bool remote_blocks = O.disc_remote_blocks && MR >= 64u;
         if ((RL & 15u) == 0u && cpr <= 64u && M >= 64u) {
             // Row length a multiple of 16 (Chain-10: 96): env bases are only 4-byte aligned (the flat length, 14 172, is not a multiple of
             // 16), so the first 16-byte boundary sits h = 0 / 4 / 8 / 12 bytes into the env.  From there every chunk starts h bytes into a
@@ -457,7 +539,8 @@ __device__ __forceinline__ void obs_env(const DevState& S, const Topo& T, const 
                 j += dj; q += dq;
                 if (j >= cpr) { j -= cpr; q += 1u; }
             }
-            const uint32_t t0 = h + (nchunks << 4), D = M + ML + MR;    // tail: the rest of connect (< 16 bytes), local, remote
+            const uint32_t t0 = h + (nchunks << 4), D = remote_blocks ? M + ML : M + ML + MR;    // tail: the rest of connect (< 16 bytes), local, remote
+            if (remote_blocks) remote_region_blocks();
             for (uint32_t b0 = t0 + lane * 4u; b0 < D; b0 += 256u) {
                 uint32_t v = 0;
 #pragma unroll
@@ -466,7 +549,21 @@ __device__ __forceinline__ void obs_env(const DevState& S, const Topo& T, const 
             }
         } else {
         uint32_t* out = reinterpret_cast<uint32_t*>(base);
-        stream_connect_dwords(out);
+        if (O.disc_blocks && M >= 64u) {
+            // connect rows that are not a multiple of 16 bytes (ToyCtf: 70): per-source blocks (above) for every whole 16-byte chunk of the
+            // region — env bases are only 4-byte aligned, the first chunk starts h bytes in —, dwords for the few bytes around them
+            const uint32_t h = (16u - (uint32_t)(reinterpret_cast<uintptr_t>(base) & 15u)) & 15u, BL = Nm * RL;
+            build_blocks(BL, O.blk_region, connect_block_dword);
+            const uint32_t nch = (M - h) >> 4, t0 = h + (nch << 4);
+            if (lane * 4u < h || (t0 + (lane - 4u) * 4u < M && lane >= 4u && lane < 8u)) {      // lanes 0..3: head dwords, lanes 4..7: tail dwords
+                const uint32_t b0 = lane < 4u ? lane * 4u : t0 + (lane - 4u) * 4u;
+                uint32_t v = 0;
+#pragma unroll
+                for (uint32_t b = 0; b < 4u; ++b) v |= byte_at(b0 + b) << (8u * b);
+                *reinterpret_cast<uint32_t*>(base + b0) = v;
+            }
+            stream_blocks(reinterpret_cast<uint4*>(base + h), nch, BL, O.blk_region, O.dBLc, h);
+        } else stream_connect_dwords(out);
         out += M >> 2;
         for (uint32_t i0 = lane * 4u; i0 < ML; i0 += 256u) {      // local[i][l], same rule as mask_local
             uint32_t v = 0;
@@ -475,7 +572,7 @@ __device__ __forceinline__ void obs_env(const DevState& S, const Topo& T, const 
             out[i0 >> 2] = v;
         }
         out += ML >> 2;
-        stream_remote_dwords(out);
+        if (remote_blocks) remote_region_blocks(); else stream_remote_dwords(out);
         }
     }
 }
@@ -619,7 +716,7 @@ __global__ __launch_bounds__(256) void obs_small_kernel(DevState S, Topo T, cons
     if (e >= S.E) return;                     // whole wavefront leaves together
     if (O.env_mask && !O.env_mask[e]) return; // wave-uniform: one wavefront per env
     const uint32_t n_triples_all = T.H().n_triples;
-    const ObsStage st = obs_stage_at(reinterpret_cast<uint8_t*>(obs_lds) + wave * obs_stage_bytes(S.N, n_triples_all), S.N, n_triples_all);
+    const ObsStage st = obs_stage_at(reinterpret_cast<uint8_t*>(obs_lds) + wave * obs_stage_bytes(S.N, n_triples_all, O.blk_region), S.N, n_triples_all);
     obs_env(S, T, C, O, digest, e, lane, st);
 }
 
@@ -633,7 +730,7 @@ __global__ __launch_bounds__(256) void obs_scan_kernel(DevState S, Topo T, const
     const uint32_t e0 = (blockIdx.x * 4u + wave) * 64u;
     if (e0 >= S.E) return;
     const uint32_t n_triples_all = T.H().n_triples;
-    const ObsStage st = obs_stage_at(reinterpret_cast<uint8_t*>(obs_lds) + wave * obs_stage_bytes(S.N, n_triples_all), S.N, n_triples_all);
+    const ObsStage st = obs_stage_at(reinterpret_cast<uint8_t*>(obs_lds) + wave * obs_stage_bytes(S.N, n_triples_all, O.blk_region), S.N, n_triples_all);
     uint64_t m = __ballot(e0 + lane < S.E && O.env_mask[e0 + lane] != 0);
     while (m) {
         const uint32_t e = e0 + (uint32_t)__builtin_ctzll(m);
