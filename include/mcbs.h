@@ -334,6 +334,13 @@ int  mcbs_observe_masked(mcbs_batch*, const mcbs_obs_buffers* obs, const uint8_t
  * blank observation).  Only the mask_* members of the buffers are used. */
 int  mcbs_action_mask(mcbs_batch*, const mcbs_obs_buffers* masks, void* stream);
 
+/* Row stride of mcbs_obs_buffers.mask_discrete in bytes for this batch (0 = dense: mcbs_discrete_action_count bytes per env, the default).
+ * The flat mask's length is rarely a multiple of a cache line (Chain-10 @12/12: 14 172 bytes), so dense rows share 128-byte lines with
+ * their neighbours; a caller that pads its rows to a multiple of 128 bytes (and aligns the array) gets every env's mask on lines of its
+ * own — the connect region is then streamed with aligned non-temporal stores like mask_connect.  Bytes of a row beyond the action count
+ * are never written.  Applies to mcbs_observe / mcbs_step_observe / mcbs_action_mask / mcbs_observe_masked / mcbs_attacker_wrapper_step. */
+int  mcbs_set_mask_discrete_stride(mcbs_batch*, size_t stride_bytes);
+
 /* StepInfo fields without stepping. */
 int  mcbs_step_info(mcbs_batch*, const mcbs_info_buffers* info, void* stream);
 

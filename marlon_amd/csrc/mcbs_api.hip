@@ -81,6 +81,7 @@ struct mcbs_batch {
     bool lds_topo = false, no_fused_masks = false, slow_masks = false, no_row_masks = false;
     bool no_block_masks = false;    // MCBS_NO_BLOCK_MASKS=1: round 2's fused mask writers (rows switched on / off per chunk)
     bool no_fused_wrapper = false;  // MCBS_NO_FUSED_WRAPPER=1: mcbs_attacker_wrapper_step keeps its three launches (tests step both)
+    size_t disc_stride = 0;         // mcbs_set_mask_discrete_stride: bytes between two envs' rows of mask_discrete (0: dense)
     bool coop = false;              // mcbs_step runs the G-lanes-per-env kernel (mcbs_step_coop.hip): more than 64 nodes, sets of 2 or 4 words
     uint32_t step_block_override = 0;
     uint8_t* arena = nullptr;       // every per-env column + bodies + init body, one allocation
@@ -544,6 +545,13 @@ extern "C" int mcbs_rewind(mcbs_batch* b, void* stream) {
     return launch_ok("rewind");
 }
 
+extern "C" int mcbs_set_mask_discrete_stride(mcbs_batch* b, size_t stride_bytes) {
+    if (!b) return fail(MCBS_EINVAL, "null batch");
+    if (stride_bytes && stride_bytes < mcbs_discrete_action_count(b)) return fail(MCBS_EINVAL, "row stride shorter than the Discrete action count");
+    b->disc_stride = stride_bytes;
+    return MCBS_OK;
+}
+
 extern "C" int mcbs_set_draw_tape(mcbs_batch* b, const double* tape, uint32_t draws_per_step) {
     if (!b) return fail(MCBS_EINVAL, "null batch");
     b->tape = tape;
@@ -760,6 +768,13 @@ static int launch_obs_inner(mcbs_batch* b, const mcbs_obs_buffers* o, hipStream_
     }
     O.fuse_discrete = dwords_ok && o->mask_discrete && ML % 4 == 0 && MR % 4 == 0 && b->C.L > 0 && b->C.R > 0 &&
                       reinterpret_cast<uintptr_t>(o->mask_discrete) % 4 == 0;
+    {   // row stride of mask_discrete: dense unless the caller padded its rows (mcbs_set_mask_discrete_stride)
+        const size_t D = M + ML + MR, stride = b->disc_stride ? b->disc_stride : D;
+        if (stride > 0xFFFFFFFFull) return fail(MCBS_ELIMIT, "mask_discrete row stride too large");
+        O.disc_stride = (uint32_t)stride;
+        if (O.fuse_discrete && stride % 4 != 0) O.fuse_discrete = 0;
+        O.nt_discrete = (O.fuse_discrete && stride % 128 == 0 && reinterpret_cast<uintptr_t>(o->mask_discrete) % 128 == 0 && M % 128 == 0) ? 1u : 0u;
+    }
     O.disc_blocks = (!b->no_block_masks && O.fuse_discrete && RL % 16 != 0 && BLc % 4 == 0 && BLc >= 16 && BLc <= 4064) ? 1u : 0u;
     if (O.disc_blocks && BLc > blk_bytes) blk_bytes = (uint32_t)BLc;
     O.disc_remote_blocks = (!b->no_block_masks && O.fuse_discrete && BLr % 4 == 0 && BLr >= 16 && BLr <= 4064) ? 1u : 0u;
@@ -849,7 +864,7 @@ static int launch_masks(mcbs_batch* b, const mcbs_obs_buffers* o, hipStream_t st
     if (o->mask_connect && (rc = launch_region<0>(b, o->mask_connect, M, 0, M, st, env_mask, masks_only))) return rc;
     if (o->mask_remote && (rc = launch_region<1>(b, o->mask_remote, MR, 0, MR, st, env_mask, masks_only))) return rc;
     if (o->mask_discrete) {   // connect | local | remote (action_masking.py:96-110)
-        const size_t D = M + ML + MR;
+        const size_t D = b->disc_stride ? b->disc_stride : M + ML + MR;       // (env stride; the regions' offsets inside a row are unchanged)
         if ((rc = launch_region<0>(b, o->mask_discrete, D, 0, M, st, env_mask, masks_only))) return rc;
         if ((rc = launch_region<2>(b, o->mask_discrete, D, M, ML, st, env_mask, masks_only))) return rc;
         if ((rc = launch_region<1>(b, o->mask_discrete, D, M + ML, MR, st, env_mask, masks_only))) return rc;

@@ -216,6 +216,8 @@ struct ObsIO {
     uint32_t fuse_connect; // mask_connect written by obs_small_kernel: 1 = 16-byte chunks, row length P*C a multiple of 16; 2 = dwords, any row
                            // length; 3 = 16-byte chunks for row lengths that are NOT a multiple of 16 (ToyCtf: 70), pattern of one lcm period;
                            // 4 = 16-byte chunks of per-source blocks in four LDS variants (stream_blocks)
+    uint32_t disc_stride;  // bytes between two envs' rows of mask_discrete (mcbs_set_mask_discrete_stride; the dense length N*N*P*C + N*L + N*N*R by default)
+    uint32_t nt_discrete;  // 1: env rows start on 128-byte lines of their own: the connect region's whole chunks use non-temporal stores
     uint32_t disc_remote_blocks;  // 1: ... and so does its remote region
     uint32_t disc_blocks;  // 1: the connect region of mask_discrete (row lengths that are not a multiple of 16) goes through per-source blocks too
     uint32_t blk_region;   // dwords per block variant in LDS (the larger of the connect / remote blocks + 16 bytes, rounded up to 16 bytes); 0: unused

@@ -450,7 +450,7 @@ __device__ __forceinline__ void obs_env(const DevState& S, const Topo& T, const 
         // three regions are streamed as dwords.
         const uint32_t RL = C.P * O.Cmax, R = C.R;
         const uint32_t M = rows * RL, ML = Nm * L, MR = rows * R;
-        int8_t* base = O.mask_discrete + (size_t)e * (M + ML + MR);
+        int8_t* base = O.mask_discrete + (size_t)e * O.disc_stride;
         const uint32_t cpr = RL >> 4;
         // value of byte b of the env's flat mask (connect | local | remote), for the few bytes not covered by whole 16-byte chunks
         auto byte_at = [&](uint32_t b) -> uint32_t {
@@ -535,7 +535,7 @@ __device__ __forceinline__ void obs_env(const DevState& S, const Topo& T, const 
                                        p.z & ((a & keep[2]) | (nx & ~keep[2])), p.w & ((a & keep[3]) | (nx & ~keep[3])));
                     }
                 }
-                out16[c] = v;
+                if (O.nt_discrete) stream_store16(out16 + c, v); else out16[c] = v;      // (uniform)
                 j += dj; q += dq;
                 if (j >= cpr) { j -= cpr; q += 1u; }
             }

@@ -24,7 +24,7 @@ EXPORTS = [
     "mcbs_batch_destroy", "mcbs_reset", "mcbs_rewind", "mcbs_step", "mcbs_step_observe", "mcbs_observe", "mcbs_observe_masked", "mcbs_action_mask", "mcbs_step_info",
     "mcbs_step_many", "mcbs_rollout_random", "mcbs_attacker_wrapper_post", "mcbs_attacker_wrapper_clear", "mcbs_defender_wrapper_post", "mcbs_sample_actions", "mcbs_decode_attacker_actions", "mcbs_defender_step", "mcbs_defender_observe", "mcbs_set_draw_tape", "mcbs_state_record_bytes", "mcbs_get_state", "mcbs_set_state",
     "mcbs_timing_enable", "mcbs_timing_read", "mcbs_mask_logits", "mcbs_discrete_action_count", "mcbs_copy_rows_masked", "mcbs_attacker_wrapper_finish", "mcbs_attacker_wrapper_step",
-    "mcbs_attacker_wrapper_step_launches",
+    "mcbs_attacker_wrapper_step_launches", "mcbs_set_mask_discrete_stride",
 ]
 
 _lib = None
@@ -87,6 +87,7 @@ def load_library(path: Optional[str] = None):
     lib.mcbs_attacker_wrapper_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.mcbs_attacker_wrapper_step_launches.restype = C.c_int32
     lib.mcbs_attacker_wrapper_step_launches.argtypes = [C.c_void_p, C.c_int32]
+    lib.mcbs_set_mask_discrete_stride.argtypes = [C.c_void_p, C.c_size_t]
     lib.mcbs_timing_enable.argtypes = [C.c_void_p, C.c_int32]
     lib.mcbs_timing_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     for name in EXPORTS:
@@ -139,6 +140,7 @@ class BatchEngine:
             self._topo_h = None
             raise (ValueError if rc == -1 else McbsError)(f"mcbs_batch_create failed ({rc}): {msg}")
         self._shapes = obs_field_shapes(topo, spec)
+        self.mask_discrete_stride = 0
         self._tape = None
         f32, u8, f64, i32 = torch.float32, torch.uint8, torch.float64, torch.int32
         dev = self.device
@@ -175,8 +177,16 @@ class BatchEngine:
         out = {}
         for f in (fields or [k for k in self._shapes if k != "mask_discrete"]):
             shape, dt = self._shapes[f]
+            if f == "mask_discrete" and self.mask_discrete_stride:
+                shape = (self.mask_discrete_stride,)          # padded rows (set_mask_discrete_stride): [:, :discrete_action_count()] is the mask
             out[f] = t.zeros((self.E,) + shape, dtype=getattr(t, dt), device=self.device)
         return out
+
+    def set_mask_discrete_stride(self, stride_bytes: int) -> None:
+        """Rows of `mask_discrete` buffers handed to this engine are `stride_bytes` apart (0: dense).  A multiple of 128 puts every env's
+        mask on cache lines of its own (mcbs_set_mask_discrete_stride); alloc_obs then allocates padded rows."""
+        _check(self.lib, self.lib.mcbs_set_mask_discrete_stride(self._h, int(stride_bytes)), "mcbs_set_mask_discrete_stride")
+        self.mask_discrete_stride = int(stride_bytes)
 
     @staticmethod
     def _obs_struct(obs: dict) -> ObsBuffers:

@@ -72,6 +72,10 @@ class AttackerVecEnv:
         # to its logits with mask_logits() (mcbs_mask_logits: rebuilt on the device from the observation's digest).  The observation
         # dict then has no local_vulnerability / remote_vulnerability / connect entries and action_masks() raises.
         self.materialize_masks = bool(materialize_masks)
+        if self.materialize_masks:
+            # rows of the flat mask padded to whole 128-byte lines: dense rows (Chain-10: 14 172 bytes) share cache lines with their
+            # neighbours, which cost the Discrete observation a quarter of its write bandwidth; consumers see [:, :discrete_n] views
+            self.engine.set_mask_discrete_stride((self.discrete_n + 127) // 128 * 128)
         self._obs = self.engine.alloc_obs(FLAT_FIELDS if self.materialize_masks else FLAT_FIELDS[:-1])
         self._terminal = {k: t.zeros_like(v) for k, v in self._obs.items()}
         self._mask_split = (N * N * P * Cm, N * L, (N, N, P, Cm), (N, L), (N, N, R))
@@ -112,7 +116,7 @@ class AttackerVecEnv:
         M, ML, s_connect, s_local, s_remote = self._mask_split
         out = {}
         if "mask_discrete" in obs:
-            flat = obs["mask_discrete"]
+            flat = obs["mask_discrete"][:, :self.discrete_n]          # (rows are padded to whole cache lines)
             out = {"local_vulnerability": flat[:, M:M + ML].unflatten(1, s_local), "remote_vulnerability": flat[:, M + ML:].unflatten(1, s_remote),
                    "connect": flat[:, :M].unflatten(1, s_connect)}
         out.update({
@@ -142,7 +146,8 @@ class AttackerVecEnv:
         """[n_envs, N*N*P*C + N*L + N*N*R] bool, MaskedDiscreteAttackerWrapper order (connect, local, remote)."""
         if not self.materialize_masks:
             raise RuntimeError("this AttackerVecEnv was created with materialize_masks=False: apply the mask with mask_logits(logits)")
-        return self._obs["mask_discrete"].view(self.torch.bool)      # the int8 mask holds 0 / 1 only: a bool view, no second gigabyte
+        return self._obs["mask_discrete"].view(self.torch.bool)[:, :self.discrete_n]      # the int8 mask holds 0 / 1 only: a bool view (rows padded
+                                                                                           # to whole cache lines), no second gigabyte
 
     def mask_logits(self, logits, fill: float = -1e8):
         """`where(action_masks(), logits, fill)` in place on the device, without the mask: what MaskablePPO's MaskableCategorical does

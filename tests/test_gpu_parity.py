@@ -177,6 +177,19 @@ def test_observations_match_oracle_batched(trace):
             np.testing.assert_array_equal(obs[f].cpu().numpy(), oo[f], err_msg=f"step {t} obs {f}")
         disc = np.concatenate([oo["mask_connect"].reshape(E, -1), oo["mask_local"].reshape(E, -1), oo["mask_remote"].reshape(E, -1)], axis=1)
         np.testing.assert_array_equal(obs["mask_discrete"].cpu().numpy(), disc, err_msg=f"step {t} mask_discrete")
+    # rows padded to whole 128-byte lines (mcbs_set_mask_discrete_stride, what marlon_amd/wrappers.py allocates): the same mask in
+    # [:, :A], nothing written beyond it
+    A = eng.discrete_action_count()
+    dense = eng.action_mask(eng.alloc_obs(["mask_discrete"]))["mask_discrete"].cpu().numpy()
+    pad = (A + 127) // 128 * 128
+    eng.set_mask_discrete_stride(pad)
+    wide = eng.alloc_obs(["mask_discrete"])["mask_discrete"]
+    assert tuple(wide.shape) == (E, pad)
+    wide.fill_(7)
+    eng.action_mask({"mask_discrete": wide})
+    wn = wide.cpu().numpy()
+    np.testing.assert_array_equal(wn[:, :A], dense, err_msg="padded mask_discrete rows")
+    assert (wn[:, A:] == 7).all() and dense.any()
     eng.close()
 
 

@@ -178,8 +178,11 @@ def observe_us(eng, ring, fields, reps: int = 20, advance: int = 40):
     """us per mcbs_observe of `fields` (int8 masks and int32 fields in the reference's layout) on a batch that has been advanced by
     `advance` recorded steps, HIP events on the launch stream.  Returns (us, bytes per env, obs dict)."""
     import torch
+    if "mask_discrete" in fields and not eng.mask_discrete_stride:
+        # the flat Discrete mask as marlon_amd/wrappers.py allocates it: rows padded to whole 128-byte lines (mcbs_set_mask_discrete_stride)
+        eng.set_mask_discrete_stride((eng.discrete_action_count() + 127) // 128 * 128)
     obs = eng.alloc_obs(fields)
-    bytes_per_env = sum(v[0].numel() * v.element_size() for v in obs.values())
+    bytes_per_env = sum((eng.discrete_action_count() if k == "mask_discrete" else v[0].numel()) * v.element_size() for k, v in obs.items())
     for t in range(min(advance, ring.shape[0])):
         eng.step(ring[t], with_info=False)
     for _ in range(3):
