@@ -163,10 +163,10 @@ struct StepCfg {        // the parts of mcbs_batch_cfg the kernels read
     double   avail_term0;
     uint32_t avail_uniform, pad_u;
     // packed batches: everything an env's re-initialisation writes, as constants the step kernel reads through the scalar cache — the
-    // reset image of the body (<= 112 bytes: discovery order 16, credential cache 32, <= 16 four-byte rows), the eight sets as the one
+    // reset image of the body (<= 256 bytes: discovery order 16, credential cache 32, <= 16 four-byte rows, the learned defender's rule-list words), the eight sets as the one
     // uint4, and the number of initially owned nodes — so that the auto-reset of an env that just ended is a handful of STORES by its own
     // lane: no load behind the step's stores, no wave-level copy, no fence (bench.py `headline_with_resets`)
-    uint32_t init_image[28];
+    uint32_t init_image[64];
     uint32_t init_packed[4];
     uint32_t n_init;
     uint32_t init_image_ok;  // 0: the body does not fit init_image (learned-defender / random-events state behind the rows): wave-level copy instead

@@ -763,7 +763,7 @@ __device__ __forceinline__ void step_body(const DevState& S, const Topo& T, cons
     }
     STAMP(5);              // all stores of the step retired
     if (PHASE != 1 && PK && C.init_image_ok) {
-        // Packed batches: an env that just ended is re-initialised by its OWN lane with stores only — the body's reset image (<= 7 x 16
+        // Packed batches: an env that just ended is re-initialised by its OWN lane with stores only — the body's reset image (<= 16 x 16
         // bytes), the sets and the header come from the config through the scalar cache, the episode counter was fetched at level 1.
         // (Round 2 let the whole wavefront copy the image from memory behind a fence, like the large layouts below: with ~1 % of the
         // envs ending per step that cost every other wavefront a write-acknowledgement round trip — 6.06 vs 5.05 us per step.)
@@ -771,7 +771,7 @@ __device__ __forceinline__ void step_body(const DevState& S, const Topo& T, cons
             uint4* dst = reinterpret_cast<uint4*>(S.body + (size_t)e * S.body_stride);
             const uint32_t nv = S.body_stride >> 4;
 #pragma unroll
-            for (uint32_t i = 0; i < 7u; ++i)
+            for (uint32_t i = 0; i < 16u; ++i)
                 if (i < nv) dst[i] = make_uint4(C.init_image[4 * i], C.init_image[4 * i + 1], C.init_image[4 * i + 2], C.init_image[4 * i + 3]);
             reinterpret_cast<uint4*>(S.masks)[e] = make_uint4(C.init_packed[0], C.init_packed[1], C.init_packed[2], C.init_packed[3]);
             if (S.ring) for (uint32_t s = 0; s < 16u; ++s) S.ring[(size_t)s * S.E + e] = 0ull;

@@ -275,7 +275,7 @@ struct FusedHook {
                 uint4* dst = reinterpret_cast<uint4*>(S.body + (size_t)e * S.body_stride);
                 const uint32_t nv = S.body_stride >> 4;
 #pragma unroll
-                for (uint32_t i = 0; i < 7u; ++i)
+                for (uint32_t i = 0; i < 16u; ++i)
                     if (i < nv) dst[i] = make_uint4(C.init_image[4 * i], C.init_image[4 * i + 1], C.init_image[4 * i + 2], C.init_image[4 * i + 3]);
                 reinterpret_cast<uint4*>(S.masks)[e] = make_uint4(C.init_packed[0], C.init_packed[1], C.init_packed[2], C.init_packed[3]);
                 if (S.ring) for (uint32_t s = 0; s < 16u; ++s) S.ring[(size_t)s * S.E + e] = 0ull;

@@ -55,6 +55,8 @@ def test_topology_create_rejects_malformed_blobs_without_gpu():
     bad[int(hdr["off_slot_of"])] = 200                                                     # slot index out of range
     assert lib.mcbs_topology_create(bad.ctypes.data, bad.size, 0, C.byref(out)) == -1
     assert lib.mcbs_step(None, None, None, None, None, None) == -1                          # null arguments
+    assert lib.mcbs_rewind(None, None) == -1 and lib.mcbs_set_mask_discrete_stride(None, 128) == -1
+    assert lib.mcbs_attacker_wrapper_step_launches(None, 0) == 0
     # firewall rule sections (read on the host at batch creation and by the random-events kernels): truncated / inconsistent blobs
     from marlon_amd.samples import toy_ctf
     blob = np.frombuffer(flatten.flatten(toy_ctf.new_environment()).blob, np.uint8).copy()
