@@ -413,6 +413,7 @@ def main() -> int:
             result["headline_with_resets"] = extras_resets(W, E, K if K <= 1000 else 1000, Wm, f"cuda:{local_rank}", not args.no_graph)
             parity_ok = parity_ok and result["headline_with_resets"]["rewards_dones_and_episodes_equal_rehearsal"]
             if world == 1:
+                result["batch_sweep"] = extras_batch_sweep(W)
                 result["observe"] = extras_observe(W)
                 result["wrapper"] = extras_wrapper()
         except Exception as exc:
@@ -609,6 +610,31 @@ def extras_resets(W, E: int, K: int, Wm: int, device: str, graph: bool):
            "rewards_dones_and_episodes_equal_rehearsal": same}
     eng.close()
     return out
+
+
+def extras_batch_sweep(W, sizes=(4096, 16384, 32768, 65536, 131072), K: int = 300):
+    """The headline kernel at other batch sizes (same workload, hipGraph replay, HIP events): what part of a step is FIXED — the
+    dependent-launch gap plus one wavefront's chain of memory accesses — and what part grows with the batch.  A least-squares line
+    through the points gives `fixed_us` and `ps_per_env`; `marginal_GBps_layout` = the packed layout's 221 B per env-step over that
+    slope: the rate at which additional envs are served once the fixed part is paid (state is L2 / Infinity-Cache resident up to
+    131 072 envs, so this is not an HBM rate)."""
+    import torch
+    pts = []
+    for n in sizes:
+        ring = W.record_ring("headline", K, n_envs=n)
+        eng, topo, spec, desc = W.make_engine("headline", n_envs=n)
+        us, rewards, dones = W.graph_replay_us(eng, ring, K)
+        pts.append({"envs": n, "us_per_step": us, "env_steps_per_s": n / (us * 1e-6)})
+        eng.close()
+        del ring, rewards, dones
+        torch.cuda.empty_cache()
+    xs, ys = [p["envs"] for p in pts], [p["us_per_step"] for p in pts]
+    mx, my = sum(xs) / len(xs), sum(ys) / len(ys)
+    slope = sum((x - mx) * (y - my) for x, y in zip(xs, ys)) / sum((x - mx) ** 2 for x in xs)
+    layout = layout_bytes_per_env_step(12)
+    return {"kernel": HEADLINE_KERNEL, "steps": K, "points": pts, "fixed_us": my - slope * mx, "ps_per_env": slope * 1e6,
+            "marginal_GBps_layout": layout / (slope * 1e-6) / 1e9 if slope > 0 else None,
+            "marginal_GBps_348B_model": B_STEP / (slope * 1e-6) / 1e9 if slope > 0 else None}
 
 
 def extras_observe(W):

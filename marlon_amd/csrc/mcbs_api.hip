@@ -463,6 +463,9 @@ extern "C" int mcbs_batch_create(const mcbs_topology* topo, const mcbs_batch_cfg
     StepCfg& C = b->C;
     C.goal_reward = cfg->goal_reward; C.goal_low_availability = cfg->goal_low_availability;
     C.goal_own_atleast_percent = cfg->goal_own_atleast_percent; C.maintain_sla = cfg->maintain_sla;
+    C.goal_own_pct_min = N + 1u;
+    for (uint32_t k = 0; k <= N; ++k)
+        if (!((double)k / (double)N < cfg->goal_own_atleast_percent)) { C.goal_own_pct_min = k; break; }     // (monotone in k: N > 0)
     C.winning_reward = cfg->winning_reward; C.losing_reward = cfg->losing_reward; C.scan_probability = cfg->scan_probability;
     C.total_sla_weight = h->total_sla_weight; C.full_availability = h->full_availability; C.full_sum = h->full_sum;
     C.seed = cfg->seed; C.env_id_base = cfg->env_id_base;

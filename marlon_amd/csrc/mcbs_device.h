@@ -169,8 +169,11 @@ struct StepCfg {        // the parts of mcbs_batch_cfg the kernels read
     uint32_t init_image[64];
     uint32_t init_packed[4];
     uint32_t n_init;
+    uint32_t goal_own_pct_min;   // AttackerGoal.own_atleast_percent as a count: the smallest k with !(k / N < percent) in the reference's own
+                                 // fp64 division (env.py:1093-1095), found on the host (N + 1: never) — the kernels compare integers instead
+                                 // of dividing doubles per env and step
     uint32_t init_image_ok;  // 0: the body does not fit init_image (learned-defender / random-events state behind the rows): wave-level copy instead
-    uint32_t pad_v[2];
+    uint32_t pad_v[1];
 };
 
 // mcbs_rollout_random: the looping step kernel samples each step's action itself; passed as a kernel argument of that variant only

@@ -562,11 +562,12 @@ __device__ __forceinline__ void step_body(const DevState& S, const Topo& T, cons
     // the goal / termination constants too (one pin for all, so that the loads go out together): fetched where they are used they
     // were five serial scalar-load waits on the way to the step's stores; here their latency disappears behind the vector loads'
     unsigned long long g_reward = __double_as_longlong(C.goal_reward), g_low = __double_as_longlong(C.goal_low_availability),
-                       g_pct = __double_as_longlong(C.goal_own_atleast_percent), g_sla = __double_as_longlong(C.maintain_sla),
+                       g_sla = __double_as_longlong(C.maintain_sla),
                        g_win = __double_as_longlong(C.winning_reward), g_lose = __double_as_longlong(C.losing_reward);
-    uint32_t g_has = C.has_attacker_goal, g_own = C.goal_own_atleast, g_evict = C.defender_goal_eviction, g_auto = C.auto_reset, g_max = C.max_episode_steps;
+    uint32_t g_has = C.has_attacker_goal, g_own = C.goal_own_atleast, g_evict = C.defender_goal_eviction, g_auto = C.auto_reset, g_max = C.max_episode_steps,
+             g_pctmin = C.goal_own_pct_min;
     if (PHASE != 1)
-        asm volatile("" : "+s"(cL), "+s"(cR), "+s"(cP), "+s"(g_reward), "+s"(g_low), "+s"(g_pct), "+s"(g_sla), "+s"(g_win), "+s"(g_lose), "+s"(g_has),
+        asm volatile("" : "+s"(cL), "+s"(cR), "+s"(cP), "+s"(g_reward), "+s"(g_low), "+s"(g_pctmin), "+s"(g_sla), "+s"(g_win), "+s"(g_lose), "+s"(g_has),
                           "+s"(g_own), "+s"(g_evict), "+s"(g_auto), "+s"(g_max));
     else asm volatile("" : "+s"(cL), "+s"(cR), "+s"(cP));
     if (!TOPO_LDS) tb = T.hot;
@@ -710,7 +711,7 @@ __device__ __forceinline__ void step_body(const DevState& S, const Topo& T, cons
         {
             // goals (env.py:1080-1116) on the state AFTER the defender acted, availability from BEFORE its scan
             const bool attacker_goal = (g_has != 0) & !(h1.x < __longlong_as_double(g_reward)) & !(ln.owned < g_own) &
-                                       !((double)ln.owned / (double)S.N < __longlong_as_double(g_pct)) &
+                                       !(ln.owned < g_pctmin) &
                                        !(def_avail && h1.y >= __longlong_as_double(g_low));
             const bool sla_broken = def_avail && h1.y < __longlong_as_double(g_sla);
             const bool evicted = (g_evict != 0) & (ln.owned == 0);

@@ -47,6 +47,8 @@ def test_bench_line_contract_small_run():
     assert [x["name"] for x in b["configs"]] == ["config3", "config4", "config5"] and all(x["us_per_step"] > 0 for x in b["configs"])
     assert all(x["n_gpus"] == 1 and x["rehearsal_equal"] is True for x in b["configs"])
     assert {x["name"] for x in b["observe"]} >= {"headline", "headline_discrete", "headline_mask_logits", "config3"}
+    sw = b["batch_sweep"]                                # fixed part of a step vs the part that grows with the batch
+    assert [p["envs"] for p in sw["points"]] == [4096, 16384, 32768, 65536, 131072] and 1.0 < sw["fixed_us"] < 5.0 and sw["ps_per_env"] > 0
     w = b["wrapper"]
     assert len(w) == 3 and w[0]["last_reward_sum"] == w[1]["last_reward_sum"] == w[2]["last_reward_sum"]
     assert w[1]["us_per_step"] < w[0]["us_per_step"] and w[2]["us_per_step"] < w[0]["us_per_step"]
