@@ -24,7 +24,7 @@ def _flat_equal(obs, i, z, prefix, t, ctx):
         np.testing.assert_array_equal(np.asarray(obs[k][i]).reshape(-1), np.asarray(ref(k)).reshape(-1), err_msg=f"{ctx} {k}")
 
 
-def _make(name, n_envs=1):
+def _make(name, n_envs=1, **extra):
     from marlon_amd import cyberbattle_env as ce
     from marlon_amd._abi import RNG_TAPE
     from marlon_amd.vecenv import MarlonVecEnv
@@ -36,7 +36,7 @@ def _make(name, n_envs=1):
     att = AttackerVecEnv(topo, n_envs, maximum_node_count=sj["maximum_node_count"], maximum_total_credentials=sj["maximum_total_credentials"],
                          attacker_goal=ce.AttackerGoal(**sj["attacker_goal"]), defender_constraint=ce.DefenderConstraint(sj["maintain_sla"]),
                          defender_agent=None if d is None else ce.ScanAndReimageCompromisedMachines(d[1], d[2], d[3]),
-                         max_timesteps=sj["max_timesteps"], discrete=sj["discrete"], rng_kind=RNG_TAPE)
+                         max_timesteps=sj["max_timesteps"], discrete=sj["discrete"], rng_kind=RNG_TAPE, **extra)
     return z, sj, MarlonVecEnv(att)
 
 
@@ -87,6 +87,50 @@ def test_vecenv_call_sequence_reproduces_reference_wrapper_traces(name):
     assert len(ep_info_buffer) == int(z["was_reset"].sum()) > 0
     assert env.get_attr("max_timesteps") == [sj["max_timesteps"]] and env.env_is_wrapped(object) == [False]
     assert env.get_attr("timesteps") == [length]
+    env.close()
+
+
+@pytest.mark.parametrize("name", WRAP)
+def test_one_launch_wrapper_step_reproduces_reference_wrapper_traces(name):
+    """The traces captured from the reference's own AttackerEnvWrapper / MaskedDiscreteAttackerWrapper, replayed through the wrapper
+    WITHOUT materialised masks — for these small topologies the whole step is then ONE launch (mcbs_wrapper_fused.hip): rewards, flags,
+    every non-mask observation field, terminal and reset observations, and the action mask itself, recovered from mcbs_mask_logits on the
+    digest the launch left (attack_wrapper.py:255-372, action_masking.py:90-142)."""
+    import torch
+    z, sj, env = _make(name, materialize_masks=False)
+    assert env.venv.engine.wrapper_step_launches(False) == 1
+    nomask = [k for k in FLAT if k not in ("local_vulnerability", "remote_vulnerability", "connect")]
+
+    def small_equal(obs, ref_prefix, t, ctx):
+        from marlon_amd.cyberbattle_env import SCALAR_KEYS
+        ref = (lambda k: z[ref_prefix + k]) if t is None else (lambda k: z[ref_prefix + k][t])
+        assert [int(np.asarray(obs[k]).reshape(-1)[0]) for k in SCALAR_KEYS] == ref("scalars").tolist(), ctx + " scalars"
+        for k in nomask:
+            np.testing.assert_array_equal(np.asarray(obs[k][0]).reshape(-1), np.asarray(ref(k)).reshape(-1), err_msg=f"{ctx} {k}")
+
+    small_equal(env.reset(), "first_", None, name + " reset")
+    A = env.venv.discrete_n
+    resets = 0
+    for t in range(len(z["reward"])):
+        ctx = f"{name} step {t} (one launch)"
+        if z["tape"].size:
+            env.venv.engine.set_draw_tape(z["tape"][t:t + 1])
+        new_obs, rewards, dones, infos = env.step(np.asarray(z["action"][t]).reshape((1,) if sj["discrete"] else (1, 10)))
+        assert float(rewards[0]) == z["reward"][t], ctx + " reward"
+        term, trunc = bool(z["terminated"][t]), bool(z["truncated"][t])
+        assert bool(dones[0]) == (term or trunc) and infos[0]["TimeLimit.truncated"] == (trunc and not term), ctx + " flags"
+        assert infos[0]["invalid_action"] == bool(z["invalid"][t]), ctx + " interception"
+        if dones[0]:
+            small_equal({k: v[np.newaxis] for k, v in infos[0]["terminal_observation"].items()}, "", t, ctx + " terminal observation")
+            small_equal(new_obs, "after_reset_", resets, ctx + " observation after the auto-reset")
+            resets += 1
+        else:
+            small_equal(new_obs, "", t, ctx)
+            # the mask the reference's wrapper reported after this step, from the digest alone
+            logits = torch.zeros((1, A), device=env.venv.engine.device)
+            mask = (env.venv.mask_logits(logits, fill=1.0) == 0).cpu().numpy()[0]
+            assert int(mask.sum()) == z["mask_sum"][t] and zlib.crc32(mask.astype(np.int8).tobytes()) == z["mask_crc"][t], ctx + " mask from the digest"
+    assert resets == int(z["was_reset"].sum()) > 0
     env.close()
 
 
