@@ -507,7 +507,8 @@ def load_rocprof(name: str, kernel_prefix: str, bytes_per_launch: float):
         return {"file": os.path.relpath(path, REPO), "status": f"missing or unreadable ({type(exc).__name__})"}
     run = d.get("run", {})
     return {"file": os.path.relpath(path, REPO), "command": d.get("command"), "calls": k["calls"], "avg_us": k["avg_us"], "min_us": k["min_us"],
-            "max_us": k["max_us"], "frac_by_avg_us": bytes_per_launch / (k["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "max_us": k["max_us"], "median_us": k.get("median_us"), "frac_by_avg_us": bytes_per_launch / (k["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "frac_by_median_us": None if not k.get("median_us") else bytes_per_launch / (k["median_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
             "kernel_us_of_the_profiled_run": (run.get("roofline") or {}).get("kernel_us"), "ms_per_step_of_the_profiled_run": run.get("ms_per_step"),
             "csrc_matches_this_tree": d.get("csrc_sha256") == __import__("tools.workloads", fromlist=["x"]).csrc_sha256()}
 

@@ -57,6 +57,25 @@ def counter_per_kernel(d, counter):
     return {k: (sum(v) / len(v), len(v)) for k, v in agg.items()}
 
 
+def trace_percentiles(d):
+    """Per kernel: (median, p10, p90) of the dispatch durations in the kernel trace, in us — the average of a --stats table is pulled up by
+    the few launches the profiler's own time-stamping delays."""
+    fs = glob.glob(f"{d}/**/*kernel_trace.csv", recursive=True)
+    if not fs:
+        return {}
+    durs = collections.defaultdict(list)
+    for r in csv.DictReader(open(fs[0])):
+        try:
+            durs[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        except (KeyError, ValueError):
+            continue
+    out = {}
+    for k, v in durs.items():
+        v.sort()
+        out[k] = (v[len(v) // 2], v[len(v) // 10], v[(len(v) * 9) // 10])
+    return out
+
+
 def stats_rows(d):
     fs = glob.glob(f"{d}/**/*kernel_stats.csv", recursive=True)
     return list(csv.reader(open(fs[0]))) if fs else []
@@ -76,6 +95,7 @@ def main():
         from tools import workloads as W
         d = sys.argv[2].rstrip("/")
         rows = stats_rows(f"{d}/stats")
+        pct = trace_percentiles(f"{d}/stats")
         fetch = counter_per_kernel(f"{d}/fetch", "FETCH_SIZE")
         write = counter_per_kernel(f"{d}/write", "WRITE_SIZE")
         run = {}
@@ -93,6 +113,8 @@ def main():
             k = dict(kernel=name, calls=int(r[1]), avg_us=float(r[3]) / 1e3, min_us=float(r[5]) / 1e3, max_us=float(r[6]) / 1e3,
                      share_of_gpu_time_pct=float(r[4]), FETCH_SIZE_KiB_per_launch=f, WRITE_SIZE_KiB_per_launch=w,
                      pmc_dispatches=[nf, nw])
+            if name in pct:
+                k["median_us"], k["p10_us"], k["p90_us"] = pct[name]
             sq = {}
             for sub, names in (("sqi", ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR")),
                                ("sqc", ("SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"))):
