@@ -193,7 +193,7 @@ def test_observations_match_oracle_batched(trace):
     eng.close()
 
 
-@pytest.mark.parametrize("n_nodes,seed", [(3, 1), (9, 2), (16, 3), (17, 4), (33, 5), (64, 6), (65, 7), (128, 8), (129, 9), (200, 10)])
+@pytest.mark.parametrize("n_nodes,seed", [(3, 1), (9, 2), (16, 3), (17, 4), (33, 5), (64, 6), (65, 7), (96, 11), (128, 8), (129, 9), (200, 10), (255, 12)])
 def test_random_topologies_engine_vs_oracle(n_nodes, seed):
     """The config-5 generator at sizes on both sides of every layout boundary (packed / general at 16 nodes, 1 / 2 / 4 words
     per set at 64 / 128 nodes, list heads of 16 entries, LDS-staged vs global hot image), in-env defender with Philox draws,

@@ -134,6 +134,50 @@ def test_one_launch_wrapper_step_reproduces_reference_wrapper_traces(name):
     env.close()
 
 
+def test_one_launch_wrapper_step_at_the_headline_batch_size(monkeypatch):
+    """65 536 Chain-10 envs (the batch bench.py's `wrapper` leg times): the one-launch step against round 2's three launches, actions a
+    masked-greedy policy on random scores (masks from mcbs_mask_logits on the digests) with a share of intercepted ones, truncation at 30
+    steps so that thousands of envs end and are re-initialised inside the launches: every output, observation, terminal observation,
+    counter and the engines' canonical state at the end."""
+    import torch
+    from marlon_amd.samples import chainpattern
+    from marlon_amd.wrappers import AttackerVecEnv
+    from tests.test_gpu_parity import _compare_states
+    E = 65536
+    kw = dict(maximum_node_count=12, maximum_total_credentials=12, discrete=True, max_timesteps=30, materialize_masks=False)
+    fused = AttackerVecEnv(chainpattern.new_environment(10), E, **kw)
+    monkeypatch.setenv("MCBS_NO_FUSED_WRAPPER", "1")
+    three = AttackerVecEnv(chainpattern.new_environment(10), E, **kw)
+    monkeypatch.delenv("MCBS_NO_FUSED_WRAPPER")
+    assert fused.engine.wrapper_step_launches(False) == 1 and three.engine.wrapper_step_launches(False) == 3
+    dev = fused.engine.device
+    g = torch.Generator(device=dev).manual_seed(11)
+    ended = 0
+    for t in range(70):
+        scores = torch.rand((E, fused.discrete_n), generator=g, device=dev)
+        a = three.mask_logits(scores, fill=-1.0).argmax(dim=1)                   # uniform over the valid actions of each env
+        a[t % 13::13] = fused.discrete_n - 1                                     # every 13th env: an undiscovered node index (intercepted)
+        del scores
+        o1, r1, te1, tr1, i1 = fused.step(a)
+        o2, r2, te2, tr2, i2 = three.step(a)
+        ctx = f"step {t}"
+        assert torch.equal(r1, r2) and torch.equal(te1, te2) and torch.equal(tr1, tr2), ctx + " rewards / flags"
+        for k in i1:
+            assert torch.equal(i1[k], i2[k]), f"{ctx} info {k}"
+        for k in o1:
+            assert torch.equal(o1[k], o2[k]), f"{ctx} observation {k}"
+        if t % 10 == 9:
+            for k, x in fused.terminal_observation.items():
+                assert torch.equal(x, three.terminal_observation[k]), f"{ctx} terminal observation {k}"
+            for k in ("timesteps", "valid_action_count", "invalid_action_count", "episode_returns"):
+                assert torch.equal(getattr(fused, k), getattr(three, k)), f"{ctx} wrapper counter {k}"
+        ended += int((te1 | tr1).sum())
+    assert ended >= 2 * E
+    _compare_states(fused.engine.get_state(), three.engine.get_state(), "after 70 steps")
+    fused.close()
+    three.close()
+
+
 def test_vecenv_batch_matches_the_wrapper_it_adapts():
     """2 048 envs, Discrete actions sampled from the masks obtained through env_method: the adapter's 4-tuple, per-env infos, episode
     statistics and terminal observations against the same AttackerVecEnv stepped directly, and tensors instead of arrays with
