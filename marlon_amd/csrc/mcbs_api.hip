@@ -1222,6 +1222,24 @@ extern "C" int mcbs_defender_step(mcbs_batch* b, const int64_t* actions, uint8_t
     return launch_defender_obs(b, obs, st);
 }
 
+extern "C" int mcbs_defender_wrapper_step(mcbs_batch* b, const int64_t* actions, const mcbs_defender_obs* obs, const mcbs_defender_wrapper_buffers* w,
+                                          const mcbs_defender_wrapper_cfg* cfg, void* stream) {
+    if (!b || !actions || !w || !cfg) return fail(MCBS_EINVAL, "null argument");
+    MCBS_ON_DEVICE(b);
+    if (b->cfg.defender_kind != MCBS_DEFENDER_EXTERNAL) return fail(MCBS_ESTATE, "batch was not created with MCBS_DEFENDER_EXTERNAL");
+    const void* const* p = reinterpret_cast<const void* const*>(w);
+    for (size_t i = 0; i < sizeof(*w) / sizeof(void*); ++i) if (!p[i]) return fail(MCBS_EINVAL, "mcbs_defender_wrapper_buffers: every array is required");
+    hipStream_t st = (hipStream_t)stream;
+    b->all_fresh = false;
+    const dim3 grid((b->S.E + 127) / 128), block(128);
+    if (b->S.WT == 1) hipLaunchKernelGGL((defender_turn_post_kernel<1>), grid, block, 0, st, b->S, b->T, b->C_dev, actions, *w, *cfg);
+    else if (b->S.WT == 2) hipLaunchKernelGGL((defender_turn_post_kernel<2>), grid, block, 0, st, b->S, b->T, b->C_dev, actions, *w, *cfg);
+    else hipLaunchKernelGGL((defender_turn_post_kernel<4>), grid, block, 0, st, b->S, b->T, b->C_dev, actions, *w, *cfg);
+    int rc = launch_ok("defender turn + reward shaping");
+    if (rc || !obs) return rc;
+    return launch_defender_obs(b, obs, st);
+}
+
 extern "C" int mcbs_defender_observe(mcbs_batch* b, const mcbs_defender_obs* obs, void* stream) {
     if (!b || !obs) return fail(MCBS_EINVAL, "null argument");
     MCBS_ON_DEVICE(b);

@@ -265,34 +265,4 @@ __global__ __launch_bounds__(64) void decode_step1_kernel(DevState S, Topo T, co
     step_body<1, WTP, false, DEFK, false>(S, T, Cp, io, RollArgs{}, nh);
 }
 
-// DefenderEnvWrapper.step's reward shaping (defend_wrapper.py:228-282), same order of fp64 operations as the host version it replaces
-__global__ __launch_bounds__(256) void defender_wrapper_post_kernel(uint32_t E, mcbs_defender_wrapper_buffers w, mcbs_defender_wrapper_cfg c) {
-    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= E) return;
-    const bool valid = w.valid[e] != 0;
-    if (valid) w.valid_action_count[e] += 1; else w.invalid_action_count[e] += 1;
-    const double avail = w.availability[e];
-    double reward = (valid ? 0.0 : 1.0) * c.invalid_action_penalty;
-    reward = reward - (w.attacker_has_cyber_reward[e] ? (double)w.attacker_last_cyber_reward[e] : 0.0);
-    const double worsening = w.prev_availability[e] - avail;
-    const bool breached = avail < c.maintain_sla, had = w.has_breached_sla[e] != 0;
-    const bool first = breached && !had;
-    reward = reward + (first ? 1.0 : 0.0) * c.loss_reward;
-    const bool again = breached && had && worsening > 0.0;
-    reward = reward + (again ? __dmul_rn(-c.sla_worsening_penalty_scale, worsening) : 0.0);   // (a separately rounded product, as on the host)
-    bool terminated = c.reset_on_constraint_broken ? first : false;
-    w.has_breached_sla[e] = breached ? 1 : 0;
-    w.prev_availability[e] = avail;
-    const bool won = w.evicted[e] != 0;
-    if (won) reward = c.winning_reward;
-    terminated = terminated || won;
-    const int32_t t = w.timesteps[e] + 1;
-    w.timesteps[e] = t;
-    w.reward[e] = reward;
-    w.terminated[e] = terminated ? 1 : 0;
-    w.truncated[e] = t >= c.max_timesteps ? 1 : 0;
-    w.breached[e] = breached ? 1 : 0;
-    w.won[e] = won ? 1 : 0;
-}
-
 } // namespace mcbs

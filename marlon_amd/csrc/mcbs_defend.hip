@@ -16,12 +16,10 @@
 
 namespace mcbs {
 
+// One env's defender turn (env e < S.E).  -> ok (the action was valid), avail (availability after the tick), evicted
 template <int WT>
-__global__ __launch_bounds__(128) void defender_kernel(DevState S, Topo T, const StepCfg* __restrict__ Cp, const int64_t* actions,
-                                                       uint8_t* valid_out, double* avail_out, uint8_t* evicted_out) {
-    const StepCfg& C = *Cp;
-    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= S.E) return;
+__device__ __forceinline__ void defender_turn(const DevState& S, const Topo& T, const StepCfg& C, const int64_t* actions, uint32_t e,
+                                              bool& ok_out, double& avail_out, bool& evicted_out) {
     const uint4 h0 = S.h0[e];
     double2 h1 = S.h1[e];
     uint8_t* body = S.body + (size_t)e * S.body_stride;
@@ -49,9 +47,7 @@ __global__ __launch_bounds__(128) void defender_kernel(DevState S, Topo T, const
     for (int i = 0; i < 12; ++i) a[i] = ap[i];
     const int kind = (int)a[0];
     if (kind <= -2) {                                                // env not taking part in this turn (e.g. its episode just ended)
-        if (valid_out) valid_out[e] = 0;
-        if (avail_out) avail_out[e] = h1.y;
-        if (evicted_out) evicted_out[e] = 0;
+        ok_out = false; avail_out = h1.y; evicted_out = false;
         return;
     }
     const int node = kind == 0 ? (int)a[1] : kind == 1 ? (int)a[2] : kind == 2 ? (int)a[5] : kind == 3 ? (int)a[8] : kind == 4 ? (int)a[10] : -1;
@@ -98,9 +94,69 @@ __global__ __launch_bounds__(128) void defender_kernel(DevState S, Topo T, const
                 if (WT == 1 || ln.m[k][w] != m0[k][w]) S.put(k, (uint32_t)w, e, ln.m[k][w]);
         }
     }
+    ok_out = ok; avail_out = h1.y;
+    evicted_out = C.defender_goal_eviction && ln.owned == 0;          // __defender_goal_reached (env.py:1112-1116)
+}
+
+template <int WT>
+__global__ __launch_bounds__(128) void defender_kernel(DevState S, Topo T, const StepCfg* __restrict__ Cp, const int64_t* actions,
+                                                       uint8_t* valid_out, double* avail_out, uint8_t* evicted_out) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= S.E) return;
+    bool ok, evicted;
+    double avail;
+    defender_turn<WT>(S, T, *Cp, actions, e, ok, avail, evicted);
     if (valid_out) valid_out[e] = ok ? 1 : 0;
-    if (avail_out) avail_out[e] = h1.y;
-    if (evicted_out) evicted_out[e] = (C.defender_goal_eviction && ln.owned == 0) ? 1 : 0;   // __defender_goal_reached (env.py:1112-1116)
+    if (avail_out) avail_out[e] = avail;
+    if (evicted_out) evicted_out[e] = evicted ? 1 : 0;
+}
+
+// DefenderEnvWrapper.step's reward shaping (defend_wrapper.py:228-282) for one env, from the turn's results (in registers or loaded)
+__device__ __forceinline__ void defender_shape(const mcbs_defender_wrapper_buffers& w, const mcbs_defender_wrapper_cfg& c, uint32_t e, bool valid, double avail,
+                                               bool won) {
+    if (valid) w.valid_action_count[e] += 1; else w.invalid_action_count[e] += 1;
+    double reward = (valid ? 0.0 : 1.0) * c.invalid_action_penalty;
+    reward = reward - (w.attacker_has_cyber_reward[e] ? (double)w.attacker_last_cyber_reward[e] : 0.0);
+    const double worsening = w.prev_availability[e] - avail;
+    const bool breached = avail < c.maintain_sla, had = w.has_breached_sla[e] != 0;
+    const bool first = breached && !had;
+    reward = reward + (first ? 1.0 : 0.0) * c.loss_reward;
+    const bool again = breached && had && worsening > 0.0;
+    reward = reward + (again ? __dmul_rn(-c.sla_worsening_penalty_scale, worsening) : 0.0);   // (a separately rounded product, as on the host)
+    bool terminated = c.reset_on_constraint_broken ? first : false;
+    w.has_breached_sla[e] = breached ? 1 : 0;
+    w.prev_availability[e] = avail;
+    if (won) reward = c.winning_reward;
+    terminated = terminated || won;
+    const int32_t t = w.timesteps[e] + 1;
+    w.timesteps[e] = t;
+    w.reward[e] = reward;
+    w.terminated[e] = terminated ? 1 : 0;
+    w.truncated[e] = t >= c.max_timesteps ? 1 : 0;
+    w.breached[e] = breached ? 1 : 0;
+    w.won[e] = won ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void defender_wrapper_post_kernel(uint32_t E, mcbs_defender_wrapper_buffers w, mcbs_defender_wrapper_cfg c) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    defender_shape(w, c, e, w.valid[e] != 0, w.availability[e], w.evicted[e] != 0);
+}
+
+// mcbs_defender_wrapper_step: the defender's turn AND the wrapper's reward shaping in one launch (the shaping takes the turn's results
+// from registers; valid / availability / evicted are still written for the caller)
+template <int WT>
+__global__ __launch_bounds__(128) void defender_turn_post_kernel(DevState S, Topo T, const StepCfg* __restrict__ Cp, const int64_t* actions,
+                                                                 mcbs_defender_wrapper_buffers w, mcbs_defender_wrapper_cfg c) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= S.E) return;
+    bool ok, evicted;
+    double avail;
+    defender_turn<WT>(S, T, *Cp, actions, e, ok, avail, evicted);
+    const_cast<uint8_t*>(w.valid)[e] = ok ? 1 : 0;
+    const_cast<double*>(w.availability)[e] = avail;
+    const_cast<uint8_t*>(w.evicted)[e] = evicted ? 1 : 0;
+    defender_shape(w, c, e, ok, avail, evicted);
 }
 
 __global__ __launch_bounds__(256) void defender_obs_kernel(DevState S, Topo T, int8_t* infected, int8_t* fw_in, int8_t* fw_out,

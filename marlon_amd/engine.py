@@ -24,7 +24,7 @@ EXPORTS = [
     "mcbs_batch_destroy", "mcbs_reset", "mcbs_rewind", "mcbs_step", "mcbs_step_observe", "mcbs_observe", "mcbs_observe_masked", "mcbs_action_mask", "mcbs_step_info",
     "mcbs_step_many", "mcbs_rollout_random", "mcbs_attacker_wrapper_post", "mcbs_attacker_wrapper_clear", "mcbs_defender_wrapper_post", "mcbs_sample_actions", "mcbs_decode_attacker_actions", "mcbs_defender_step", "mcbs_defender_observe", "mcbs_set_draw_tape", "mcbs_state_record_bytes", "mcbs_get_state", "mcbs_set_state",
     "mcbs_timing_enable", "mcbs_timing_read", "mcbs_mask_logits", "mcbs_discrete_action_count", "mcbs_copy_rows_masked", "mcbs_attacker_wrapper_finish", "mcbs_attacker_wrapper_step",
-    "mcbs_attacker_wrapper_step_launches", "mcbs_set_mask_discrete_stride",
+    "mcbs_attacker_wrapper_step_launches", "mcbs_set_mask_discrete_stride", "mcbs_defender_wrapper_step",
 ]
 
 _lib = None
@@ -73,6 +73,7 @@ def load_library(path: Optional[str] = None):
     lib.mcbs_decode_attacker_actions.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.mcbs_defender_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(DefenderObs), C.c_void_p]
     lib.mcbs_defender_observe.argtypes = [C.c_void_p, C.POINTER(DefenderObs), C.c_void_p]
+    lib.mcbs_defender_wrapper_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.mcbs_set_draw_tape.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
     lib.mcbs_state_record_bytes.restype = C.c_size_t
     lib.mcbs_state_record_bytes.argtypes = [C.c_void_p]
@@ -423,6 +424,12 @@ class BatchEngine:
         _check(self.lib, self.lib.mcbs_defender_step(self._h, a.data_ptr(), v.data_ptr(), av.data_ptr(), ev.data_ptr(),
                                                      C.byref(o) if o is not None else None, self._stream()), "mcbs_defender_step")
         return v, av, ev
+
+    def defender_wrapper_step(self, actions12, obs_struct, bufs, cfg) -> None:
+        """mcbs_defender_wrapper_step: the defender's turn + the wrapper's reward shaping in one launch, then the observation.
+        `actions12`: int64 device tensor [E, 12]; `obs_struct`: a DefenderObs block (or None); `bufs` / `cfg`: argument blocks built once."""
+        _check(self.lib, self.lib.mcbs_defender_wrapper_step(self._h, actions12.data_ptr(), C.byref(obs_struct) if obs_struct is not None else None,
+                                                             C.byref(bufs), C.byref(cfg), self._stream()), "mcbs_defender_wrapper_step")
 
     def defender_observe(self, obs: dict) -> dict:
         o = DefenderObs(**{k: x.data_ptr() for k, x in obs.items()})

@@ -267,8 +267,8 @@ class DefenderVecEnv:
     marlon/defender_agents/defender.py) for the batch an `AttackerVecEnv(..., learned_defender=True)` owns: the two
     wrappers share one environment batch, as in MultiAgentUniverse.build (multiagent_universe.py:160-199).
 
-    step(actions[E,12]) = validity check + executeAction on the device (`mcbs_defender_step`), then the wrapper's reward
-    shaping (defend_wrapper.py:228-282): invalid-action penalty, minus the attacker's last environment reward, a one-time
+    step(actions[E,12]) = validity check + executeAction AND the wrapper's reward shaping in one launch, then the observation
+    (`mcbs_defender_wrapper_step`).  The shaping (defend_wrapper.py:228-282): invalid-action penalty, minus the attacker's last environment reward, a one-time
     `loss_reward` when availability first drops below `maintain_sla` (terminating if reset_on_constraint_broken), a
     worsening penalty while breached, `winning_reward` on eviction; truncation at max_timesteps.
     The learned defender always acts on the live environment."""
@@ -296,11 +296,11 @@ class DefenderVecEnv:
         self.prev_availability = t.ones(E, dtype=t.float64, device=dev)
         self.valid_action_count = t.zeros(E, dtype=t.int64, device=dev)
         self.invalid_action_count = t.zeros(E, dtype=t.int64, device=dev)
-        self._wb = self._evicted = None
-        # use_graph: the defender's turn (validity + executeAction + observation, reward shaping) captured once and replayed as one
-        # hipGraph; outputs are then the wrapper's own buffers (overwritten by the next step)
+        self._evicted = None
+        self._ring, self._slot = None, 0
+        # use_graph: outputs are the wrapper's own persistent buffers (overwritten by the next step) and the actions are copied into a
+        # persistent buffer; the turn's two launches are issued directly (see step)
         self.use_graph = bool(use_graph)
-        self._graph = None
         self._act_in = t.zeros((E, 12), dtype=t.int64, device=dev)
         self.reset()
 
@@ -321,61 +321,45 @@ class DefenderVecEnv:
         self.prev_availability.copy_(t.where(keep, self.prev_availability, avail))    # in place: the fused shaping launch holds its address
         return self._obs
 
-    def _step_device(self, actions, out=None):
-        t = self.torch
-        valid, avail, evicted = self.engine.defender_step(actions, self._obs, out=out)
-        if self._wb is None:        # reward shaping (defend_wrapper.py:228-282) for the whole batch in one launch
-            from ._abi import DefenderWrapperBuffers, DefenderWrapperCfg
-            E, dev = self.num_envs, self.engine.device
-            self._out = dict(reward=t.zeros(E, dtype=t.float64, device=dev), terminated=t.zeros(E, dtype=t.uint8, device=dev),
-                             truncated=t.zeros(E, dtype=t.uint8, device=dev), breached=t.zeros(E, dtype=t.uint8, device=dev),
-                             won=t.zeros(E, dtype=t.uint8, device=dev))
-            self._wb = DefenderWrapperBuffers(*[x.data_ptr() for x in (
-                valid, avail, evicted, self.attacker.has_cyber_reward, self.attacker.last_cyber_reward, self.timesteps, self.valid_action_count,
-                self.invalid_action_count, self.has_breached_sla, self.prev_availability, self._out["reward"], self._out["terminated"],
-                self._out["truncated"], self._out["breached"], self._out["won"])])
-            self._wc = DefenderWrapperCfg(self.invalid_action_penalty, self.loss_reward, self.sla_worsening_penalty_scale, self.maintain_sla,
-                                          self.winning_reward, int(self.reset_on_constraint_broken), self.max_timesteps)
-        self.engine.defender_wrapper_post(self._wb, self._wc)
-        return valid, avail
-
     def step(self, actions):
         """-> (observation dict, reward f64 [E], terminated u8 [E], truncated u8 [E], info)."""
         t = self.torch
         if self.use_graph:
+            # (persistent outputs, actions copied into a persistent buffer — what a captured turn offered; the turn itself is two
+            # launches issued directly: replaying them from a hipGraph cost the device more than the launches it wraps, 23 vs 12 us
+            # per turn at 16 384 ToyCtf envs)
             a = actions if isinstance(actions, t.Tensor) else t.as_tensor(np.asarray(actions))
             self._act_in.copy_(a.to(device=self.engine.device).reshape(self._act_in.shape), non_blocking=True)
-            if self._graph is None:
-                self._io = self._step_device(self._act_in)             # this turn runs eagerly ...
-                t.cuda.synchronize(self.engine.device)
-                g = t.cuda.CUDAGraph()
-                side = t.cuda.Stream(device=self.engine.device)
-                side.wait_stream(t.cuda.current_stream(self.engine.device))
-                with t.cuda.stream(side):
-                    with t.cuda.graph(g, stream=side):
-                        self._step_device(self._act_in)
-                t.cuda.current_stream(self.engine.device).wait_stream(side)
-                self._graph = g                                        # ... and is captured for the turns to come
-            else:
-                self._graph.replay()
-            valid, avail = self._io
-            info = {"valid_action": valid.view(t.bool), "network_availability": avail, "sla_breached": self._out["breached"].view(t.bool),
-                    "defender_won": self._out["won"].view(t.bool)}
-            return self._obs, self._out["reward"], self._out["terminated"], self._out["truncated"], info
-        # eager: this turn's outputs are tensors of their own, written by the two launches directly (no clones of persistent buffers)
+            actions = self._act_in
+        # eager: ONE library call per turn (mcbs_defender_wrapper_step: the turn and the reward shaping in one launch, then the observation);
+        # the turn's outputs alternate between two sets of tensors allocated once (valid until the turn after next)
         E, dev = self.num_envs, self.engine.device
-        if self._evicted is None:
+        if self._ring is None:
+            from ._abi import DefenderObs, DefenderWrapperBuffers, DefenderWrapperCfg
             self._evicted = t.zeros(E, dtype=t.uint8, device=dev)
-        fresh = dict(valid=t.empty(E, dtype=t.uint8, device=dev), availability=t.empty(E, dtype=t.float64, device=dev),
-                     reward=t.empty(E, dtype=t.float64, device=dev), terminated=t.empty(E, dtype=t.uint8, device=dev),
-                     truncated=t.empty(E, dtype=t.uint8, device=dev), breached=t.empty(E, dtype=t.uint8, device=dev), won=t.empty(E, dtype=t.uint8, device=dev))
-        first = self._wb is None                # the first turn builds the argument block (on buffers of its own for the shaping outputs)
-        if not first:
-            for k, x in fresh.items():
-                setattr(self._wb, k, x.data_ptr())
-            self._out = {k: fresh[k] for k in ("reward", "terminated", "truncated", "breached", "won")}
-        valid, avail = self._step_device(actions, out=(fresh["valid"], fresh["availability"], self._evicted))
-        out = {k: v.clone() for k, v in self._out.items()} if first else self._out
-        info = {"valid_action": valid.view(t.bool), "network_availability": avail, "sla_breached": out["breached"].view(t.bool),
-                "defender_won": out["won"].view(t.bool)}
-        return self._obs, out["reward"], out["terminated"], out["truncated"], info
+            self._obs_block = DefenderObs(**{k: x.data_ptr() for k, x in self._obs.items()})
+            self._wc = DefenderWrapperCfg(self.invalid_action_penalty, self.loss_reward, self.sla_worsening_penalty_scale, self.maintain_sla,
+                                          self.winning_reward, int(self.reset_on_constraint_broken), self.max_timesteps)
+            self._ring = []
+            for _ in range(2):
+                o = dict(valid=t.empty(E, dtype=t.uint8, device=dev), availability=t.empty(E, dtype=t.float64, device=dev),
+                         reward=t.empty(E, dtype=t.float64, device=dev), terminated=t.empty(E, dtype=t.uint8, device=dev),
+                         truncated=t.empty(E, dtype=t.uint8, device=dev), breached=t.empty(E, dtype=t.uint8, device=dev),
+                         won=t.empty(E, dtype=t.uint8, device=dev))
+                wb = DefenderWrapperBuffers(*[x.data_ptr() for x in (
+                    o["valid"], o["availability"], self._evicted, self.attacker.has_cyber_reward, self.attacker.last_cyber_reward, self.timesteps,
+                    self.valid_action_count, self.invalid_action_count, self.has_breached_sla, self.prev_availability, o["reward"], o["terminated"],
+                    o["truncated"], o["breached"], o["won"])])
+                info = {"valid_action": o["valid"].view(t.bool), "network_availability": o["availability"], "sla_breached": o["breached"].view(t.bool),
+                        "defender_won": o["won"].view(t.bool)}
+                self._ring.append((o, wb, info))
+        if not self.use_graph:
+            self._slot ^= 1
+        o, wb, info = self._ring[self._slot]
+        a = actions if isinstance(actions, t.Tensor) else t.as_tensor(np.asarray(actions))
+        a = a.to(device=dev, dtype=t.int64).contiguous()
+        if tuple(a.shape) != (E, 12):
+            raise ValueError(f"defender actions must have shape ({E}, 12), got {tuple(a.shape)}")
+        self.engine.defender_wrapper_step(a, self._obs_block, wb, self._wc)
+        self._out = o
+        return self._obs, o["reward"], o["terminated"], o["truncated"], dict(info)
