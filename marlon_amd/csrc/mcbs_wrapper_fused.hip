@@ -11,10 +11,10 @@
 //   loads   : everything the step loads (mcbs_step.hip levels 1 and 2), the policy's action, the wrapper's counters — once;
 //   compute : lane = env for the decode, the attacker's action, the defender / goals and the wrapper's bookkeeping (mcbs_step.hip's
 //             step_body with three hook points, the same code the headline kernel runs);
-//   observe : between the attacker's action and the defender's turn each lane parks what its env's observation is made of — per
-//             discovered node (by discovery index) the known properties and privilege, per cached credential (node index, port), flags
-//             and counts — in 116 bytes of LDS, straight from the registers the step holds (the list heads are kept up to date in
-//             registers while leaked entries are appended);
+//   observe : between the attacker's action and the defender's turn each lane hands what its env's observation is made of — list heads
+//             (kept up to date in registers while leaked entries are appended), node rows, three sets, flags and counts — to the
+//             workgroup through 132 bytes of LDS, straight from the registers the step holds; after the step all four wavefronts turn
+//             the 64 hand-overs into records by discovery index (known properties, privilege, (node index, port) per cached credential);
 //   stores  : state, outputs, the re-initialisation of the envs that ended (their own lane, stores only), and then the observation of
 //             the wavefront's 64 envs STREAMED OUT COOPERATIVELY: the 64 envs' rows of each observation array are one contiguous
 //             block of memory (43 KB of property flags, 6 KB of cache rows ...), so lane L of store k writes 16 bytes at
@@ -91,7 +91,7 @@ constexpr uint32_t FM_LIVE = 1u << 16, FM_BLANK = 1u << 17, FM_ENDED = 1u << 18;
 struct FusedHook {
     static constexpr bool kAction = true, kObs = true, kFinish = true;
     const FusedArgs& A;
-    uint32_t* lds;                 // [64 x 29] stage | [1024] reset observation | [32] triple table (node | port << 16) | [16] reset digest
+    uint32_t* lds;                 // [64 x 37] records | [64 x 33] hand-overs | [1024] reset observation | [32] triple table (node | port << 16) | [16] reset digest
     uint32_t lane;                 // thread index in the workgroup; the stepping wavefront's lanes: 0..63 = env in the workgroup
     // level-1 loads
     // the policy's action: ten named scalars, not an array — a select between ELEMENTS of an array that lives in an object whose address
@@ -243,8 +243,8 @@ struct FusedHook {
         }
     }
 
-    // After the step's own stores: the wrapper's bookkeeping (wrapper_finish_body, word for word), the re-initialisation of an env that
-    // ended (own lane, stores only), then the wavefront streams its 64 envs' observations.
+    // After the step's own stores: the wrapper's bookkeeping (wrapper_finish_body, word for word) and the re-initialisation of an env that
+    // ended (own lane, stores only).  The workgroup streams the observations afterwards (wrapper_fused_kernel).
     __device__ __forceinline__ void finish(const DevState& S, const StepCfg& C, const Topo& T, uint32_t e, bool active, float reward, bool terminated,
                                            uint32_t episode) {
         const mcbs_wrapper_buffers& w = A.w;
@@ -333,7 +333,7 @@ struct FusedHook {
                     const FusedStage st = stage(env);
                     const uint32_t meta = st.meta();
                     const uint32_t v = dword_value<f>(st, idx);
-                    if (meta & FM_ENDED) { tout[q] = (int32_t)v; out[q] = (int32_t)fr[A.fresh_off[f] + idx]; }
+                    if (meta & FM_ENDED) { if (meta & FM_LIVE) tout[q] = (int32_t)v; else tout[q] = out[q]; out[q] = (int32_t)fr[A.fresh_off[f] + idx]; }
                     else if (meta & FM_LIVE) out[q] = (int32_t)v;
                 }
                 return;
@@ -364,7 +364,8 @@ struct FusedHook {
                     const uint32_t ci = n_creds - new_creds + r, c = st.cred()[ci & 15u];
                     v = have ? make_uint4(1u, ci, c & 0xFFu, c >> 8) : make_uint4(0u, 0u, 0u, 0u);
                 }
-                if (meta & FM_ENDED) { tout[q] = v; out[q] = frow[r]; }      // the episode's last observation; the env's next one is the reset observation
+                if (meta & FM_ENDED) { if (meta & FM_LIVE) tout[q] = v; else tout[q] = out[q]; out[q] = frow[r]; }      // the episode's last observation (an intercepted
+                                                                                                          // action: the one that stands); the env's next one is the reset observation
                 else if (meta & FM_LIVE) out[q] = v;                         // (an intercepted action leaves the env's observation as it was)
             }
         }
@@ -396,7 +397,7 @@ struct FusedHook {
                     else if (j == 4u) v = kind == MCBS_OUT_PRIVILEGE_ESCALATION ? (int32_t)level : 0;
                     else v = (int32_t)n_creds;
                 }
-                if (meta & FM_ENDED) { tout[q] = v; out[q] = (int32_t)fr[A.fresh_off[0] + j]; }
+                if (meta & FM_ENDED) { if (meta & FM_LIVE) tout[q] = v; else tout[q] = out[q]; out[q] = (int32_t)fr[A.fresh_off[0] + j]; }
                 else if (meta & FM_LIVE) out[q] = v;
             }
         }

@@ -520,8 +520,9 @@ def test_one_launch_wrapper_step_equals_three_launches(case, monkeypatch):
         m = ref.action_masks()
         scores = torch.rand(m.shape, generator=g, device=dev)
         a = torch.where(m, scores, torch.full_like(scores, -1.0)).argmax(dim=1)
-        if t % 7 == 3:
-            a[::9] = ref.discrete_n - 1                         # undiscovered node indices: intercepted, the env keeps its observation
+        if t % 7 == 3 or (t + 1) % kw["max_timesteps"] == 0:    # (also on the step many envs are truncated at: the terminal observation of an
+            a[::9] = ref.discrete_n - 1                         # intercepted env is the one that STANDS, taken before the defender's last turn)
+                                                                # undiscovered node indices: intercepted, the env keeps its observation
         if not kw["discrete"]:                                   # the same action as a MultiDiscrete(10) row (attack_wrapper.py:206-227)
             N, Cm = kw["maximum_node_count"], kw["maximum_total_credentials"]
             M, ML = ref._mask_split[0], ref._mask_split[1]
@@ -558,5 +559,55 @@ def test_one_launch_wrapper_step_equals_three_launches(case, monkeypatch):
         if t % 30 == 29:
             _compare_states(fused.engine.get_state(), three.engine.get_state(), ctx)
     assert ended > E // 2
+    for env in (ref, fused, three):
+        env.close()
+
+
+def test_terminal_observation_of_an_intercepted_last_action_is_the_one_that_stands(monkeypatch):
+    """An action with an undiscovered node index does not step the env and returns the observation the env already had
+    (attack_wrapper.py:286-308) — also when that very step truncates the episode: the terminal observation is then that standing
+    observation, taken BEFORE the defender's turn of the last executed step (env.py:1153 vs 1156-1158), not a fresh look at the state the
+    defender has changed since.  A defender that re-images every infected node in every step makes the two differ (privilege levels of a
+    node the attacker owned in its last executed step); the one-launch step and the three-launch step must both hand out the standing one."""
+    import torch
+    from marlon_amd import cyberbattle_env as ce
+    from marlon_amd.samples import chainpattern
+    from marlon_amd.wrappers import AttackerVecEnv
+    E, T = 6000, 14
+    kw = dict(maximum_node_count=12, maximum_total_credentials=12, discrete=True, max_timesteps=T, attacker_goal=ce.AttackerGoal(own_atleast_percent=1.0),
+              defender_constraint=ce.DefenderConstraint(0.0), defender_agent=ce.ScanAndReimageCompromisedMachines(1.0, 12, 1), seed=5)
+    ref = AttackerVecEnv(chainpattern.new_environment(10), E, **kw)
+    fused = AttackerVecEnv(chainpattern.new_environment(10), E, materialize_masks=False, **kw)
+    monkeypatch.setenv("MCBS_NO_FUSED_WRAPPER", "1")
+    three = AttackerVecEnv(chainpattern.new_environment(10), E, materialize_masks=False, **kw)
+    monkeypatch.delenv("MCBS_NO_FUSED_WRAPPER")
+    assert fused.engine.wrapper_step_launches(False) == 1 and three.engine.wrapper_step_launches(False) == 3
+    dev = ref.engine.device
+    g = torch.Generator(device=dev).manual_seed(2)
+    standing = fresh_look = None
+    for t in range(T):
+        if t < T - 1:
+            m = ref.action_masks()
+            scores = torch.rand(m.shape, generator=g, device=dev)
+            a = torch.where(m, scores, torch.full_like(scores, -1.0)).argmax(dim=1)
+        else:
+            a = torch.full((E,), ref.discrete_n - 1, dtype=torch.int64, device=dev)      # intercepted in every env; the T-th wrapper step truncates
+        outs = [env.step(a.clone()) for env in (ref, fused, three)]
+        for k in outs[1][0]:
+            assert torch.equal(outs[1][0][k], outs[2][0][k]) and torch.equal(outs[1][0][k], outs[0][0][k]), f"step {t} observation {k}"
+        if t == T - 2:
+            standing = {k: v.clone() for k, v in outs[1][0].items()}
+            fresh_look = ref.engine.observe(ref.engine.alloc_obs(["nodes_privilegelevel"]))["nodes_privilegelevel"].clone()
+    never_ended = (ref.timesteps == 0) & (outs[0][3] != 0)                       # truncated by this step (their counters were just cleared)
+    assert bool(outs[1][4]["invalid_action"].all()) and int(never_ended.sum()) > E // 2
+    # the scenario is real: for some of those envs the state has moved on since the standing observation (a node owned in the last
+    # executed step has been re-imaged by the defender: a fresh look shows privilege 0 where the standing observation shows 1)
+    moved_on = (standing["nodes_privilegelevel"] != fresh_look).any(dim=1) & never_ended
+    assert int(moved_on.sum()) > 0
+    for k, x in fused.terminal_observation.items():
+        sel = never_ended
+        assert torch.equal(x[sel], three.terminal_observation[k][sel]), f"terminal observation {k}: one launch vs three"
+        assert torch.equal(x[sel], ref.terminal_observation[k][sel]), f"terminal observation {k}: vs the mask-writing wrapper"
+        assert torch.equal(x[sel], standing[k][sel]), f"terminal observation {k} is not the observation that stood"
     for env in (ref, fused, three):
         env.close()
