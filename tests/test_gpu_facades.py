@@ -328,3 +328,73 @@ def test_gym_facade_exposes_what_marlons_callers_read():
     snap.get_node("start").agent_installed = False                           # a snapshot: editing it does not touch the device state
     assert env.environment.get_node("start").agent_installed
     env.close()
+
+
+@pytest.mark.parametrize("n_nodes,masks", [(24, True), (24, False), (70, True), (70, False)])
+def test_attacker_vec_env_on_larger_topologies_against_oracle(n_nodes, masks):
+    """The batched attacker wrapper beyond the reference's sample topologies (the config-5 generator at 24 and 70 nodes: general state layout,
+    one and two words per set, action spaces too large for the fused mask writers, flat-mask rows padded to whole cache lines), with the
+    oracle as checker of the wrapper's semantics: MultiDiscrete actions drawn on the host (a share of them with undiscovered node indices:
+    intercepted), in-env ScanAndReimage, truncation and auto-reset — rewards, flags, interception, the small observation fields and (when
+    materialised) the Discrete action mask of every env that stepped and did not end.  attack_wrapper.py:255-372, action_masking.py:90-110."""
+    from marlon_amd import cyberbattle_env as ce, flatten as F, model
+    from marlon_amd.samples import random_net
+    from marlon_amd.wrappers import AttackerVecEnv
+    from oracle.oracle import Oracle
+    topo = F.flatten(random_net.build(model, n_nodes, 31))
+    E, T, MAXT = 64, 70, 25
+    Cm = max(1, len(topo.triples))
+    env = AttackerVecEnv(topo, E, maximum_node_count=n_nodes, maximum_total_credentials=Cm, maximum_discoverable_credentials_per_action=8,
+                         attacker_goal=ce.AttackerGoal(own_atleast_percent=0.7), defender_agent=ce.ScanAndReimageCompromisedMachines(0.5, 2, 3),
+                         defender_constraint=ce.DefenderConstraint(0.3), max_timesteps=MAXT, seed=13, materialize_masks=masks)
+    orc = Oracle(topo, env.spec)
+    small = ["scalars", "leaked_credentials", "credential_cache_matrix", "discovered_nodes_properties", "nodes_privilegelevel"]
+    mask_fields = ["mask_connect", "mask_local", "mask_remote"] if masks else []
+    from marlon_amd.cyberbattle_env import SCALAR_KEYS
+    rng = np.random.Generator(np.random.PCG64(9))
+    timesteps = np.zeros(E, np.int64)
+    n_disc = np.ones(E, np.int64)
+    checked = ended = 0
+    for t in range(T):
+        a = (rng.random((E, 10)) * env.nvec).astype(np.int64)
+        fix = rng.random(E) < 0.8
+        for i in (1, 3, 4, 6, 7):
+            a[fix, i] = (rng.random(fix.sum()) * n_disc[fix]).astype(np.int64)
+        kind = a[:, 0]
+        src = np.where(kind == 0, a[:, 1], np.where(kind == 1, a[:, 3], a[:, 6]))
+        tgt = np.where(kind == 0, 0, np.where(kind == 1, a[:, 4], a[:, 7]))
+        valid = (src < n_disc) & ((kind == 0) | (tgt < n_disc))
+        rows = np.zeros((E, 5), np.int32)
+        rows[:, 0] = np.where(valid, kind, 3)
+        rows[:, 1] = src
+        rows[:, 2] = np.where(kind == 0, a[:, 2], tgt)
+        rows[:, 3] = np.where(kind == 1, a[:, 5], np.where(kind == 2, a[:, 8], 0))
+        rows[:, 4] = np.where(kind == 2, a[:, 9], 0)
+        obs, r, term, trunc, info = env.step(a)
+        oo = orc.alloc_obs(small + mask_fields)
+        o = orc.step(rows, obs=oo)
+        timesteps += 1
+        ctx = f"random_net({n_nodes}) masks={masks} step {t}"
+        np.testing.assert_array_equal(r.double().cpu().numpy(), o["reward"] + np.where(valid, 0.0, -1.0), err_msg=ctx + " reward")
+        np.testing.assert_array_equal(term.cpu().numpy(), o["terminated"], err_msg=ctx + " terminated")
+        np.testing.assert_array_equal(trunc.cpu().numpy(), (timesteps >= MAXT).astype(np.uint8), err_msg=ctx + " truncated")
+        np.testing.assert_array_equal(info["invalid_action"].cpu().numpy(), ~valid, err_msg=ctx + " interception")
+        dones = (o["terminated"] != 0) | (timesteps >= MAXT)
+        keep = valid & ~dones                            # these envs' observation is this step's (pre-defender) observation
+        sel = np.flatnonzero(keep)
+        if sel.size:
+            got_scalars = np.stack([obs[k].cpu().numpy() for k in SCALAR_KEYS], axis=1)
+            np.testing.assert_array_equal(got_scalars[sel], oo["scalars"][sel], err_msg=ctx + " scalars")
+            for k in small[1:]:
+                np.testing.assert_array_equal(obs[k].cpu().numpy().reshape(E, -1)[sel], oo[k].reshape(E, -1)[sel], err_msg=f"{ctx} {k}")
+            if masks:
+                flat = np.concatenate([oo["mask_connect"].reshape(E, -1), oo["mask_local"].reshape(E, -1), oo["mask_remote"].reshape(E, -1)], axis=1)
+                np.testing.assert_array_equal(env.action_masks().cpu().numpy()[sel], flat[sel] != 0, err_msg=ctx + " action mask")
+            checked += sel.size
+        for i in np.flatnonzero(dones):
+            orc.reset(int(i))
+        ended += int(dones.sum())
+        timesteps[dones] = 0
+        n_disc = obs["discovered_node_count"].cpu().numpy().astype(np.int64)
+    assert checked > E * T // 3 and ended >= E
+    env.close()
