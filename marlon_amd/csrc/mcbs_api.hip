@@ -79,6 +79,8 @@ struct mcbs_batch {
     uint32_t* ere_lists_dev = nullptr;
     // developer switches, read ONCE at batch creation (getenv on every launch costs more than the launch itself)
     bool lds_topo = false, no_fused_masks = false, slow_masks = false, no_row_masks = false;
+    bool no_quad_obs = false;       // MCBS_NO_QUAD_OBS=1: a wavefront per env for small topologies' observations with mask fields (rounds 1-2)
+    bool force_quad_obs = false;    // MCBS_QUAD_OBS=1: obs_quad_kernel also where mask rows are whole cache lines
     bool no_block_masks = false;    // MCBS_NO_BLOCK_MASKS=1: round 2's fused mask writers (rows switched on / off per chunk)
     bool no_fused_wrapper = false;  // MCBS_NO_FUSED_WRAPPER=1: mcbs_attacker_wrapper_step keeps its three launches (tests step both)
     size_t disc_stride = 0;         // mcbs_set_mask_discrete_stride: bytes between two envs' rows of mask_discrete (0: dense)
@@ -328,6 +330,7 @@ extern "C" int mcbs_batch_create(const mcbs_topology* topo, const mcbs_batch_cfg
     b->lds_topo = getenv("MCBS_LDS_TOPO") != nullptr; b->no_fused_masks = getenv("MCBS_NO_FUSED_MASKS") != nullptr;
     b->slow_masks = getenv("MCBS_SLOW_MASKS") != nullptr; b->no_row_masks = getenv("MCBS_NO_ROW_MASKS") != nullptr;
     b->no_fused_wrapper = getenv("MCBS_NO_FUSED_WRAPPER") != nullptr; b->no_block_masks = getenv("MCBS_NO_BLOCK_MASKS") != nullptr;
+    b->no_quad_obs = getenv("MCBS_NO_QUAD_OBS") != nullptr; b->force_quad_obs = getenv("MCBS_QUAD_OBS") != nullptr;
     if (const char* ov = getenv("MCBS_STEP_BLOCK")) b->step_block_override = (uint32_t)atoi(ov);   // experiments only (64, 128 or 256)
     const uint32_t E = cfg->n_envs, N = h->n_nodes;
     DevState& S = b->S;
@@ -790,13 +793,24 @@ static int launch_obs_inner(mcbs_batch* b, const mcbs_obs_buffers* o, hipStream_
     O.dPC = fdh(O.conn_pc); O.dCPR = fdh(RL >> 4);
     const uint32_t obs_shm = 4u * obs_stage_bytes(b->S.N, b->topo->H()->n_triples, O.blk_region);
     const bool no_masks = !o->mask_local && !o->mask_remote && !o->mask_connect && !o->mask_discrete;
-    if (!env_mask && !masks_only && no_masks && b->S.NW == 1u && b->S.N <= 16u && O.Nmax <= 16u && O.Cmax <= 16u && b->topo->H()->n_triples <= 15u &&
-        b->cfg.defender_kind != MCBS_DEFENDER_RANDOM_EVENTS && !b->no_fused_masks) {
+    const bool groups_ok = !env_mask && !masks_only && b->S.NW == 1u && b->S.N <= 16u && O.Nmax <= 16u && O.Cmax <= 16u &&
+                           b->topo->H()->n_triples <= 15u && b->cfg.defender_kind != MCBS_DEFENDER_RANDOM_EVENTS && !b->no_fused_masks;
+    if (groups_ok && no_masks) {
         // ~1 KB per env, no mask field: sixteen lanes per env instead of a wavefront (mcbs_obs.hip obs_tiny_kernel)
         hipLaunchKernelGGL(obs_tiny_kernel, dim3((b->S.E + 15u) / 16u), dim3(256), 0, st, b->S, b->T, b->C_dev, O, b->digest);
         return launch_ok("obs_tiny");
     }
-    if (env_mask) {     // sparse by nature (the envs a VecEnv just reset): 64 envs' mask bytes per wavefront
+    // ... with mask fields: the small fields by 16-lane groups, the masks of the wavefront's four envs one after the other (obs_quad_kernel).
+    // Measured (tools/obs_field_matrix.py, profiles/round3_notes.md section 7): ToyCtf's whole observation 43 -> 40 us at 16 384 envs and
+    // 190 -> 145 us at 65 536 (its 10 080-byte mask rows share cache lines with their neighbours, and four envs' small fields go out in one
+    // store instead of four partial lines); Chain-10, whose mask rows are whole 128-byte lines written with non-temporal stores, streams
+    // ~10 % FASTER with a wavefront per env (152-168 against 171-185 us at 65 536 envs) and keeps it.  MCBS_QUAD_OBS=1 / MCBS_NO_QUAD_OBS=1
+    // force one or the other.
+    const bool line_rows = (o->mask_connect && O.nt_connect) || (o->mask_discrete && O.nt_discrete);
+    if (groups_ok && !b->no_quad_obs && (!line_rows || b->force_quad_obs)) {
+        const uint32_t quad_shm = 4u * (272u + 1040u + 16u * O.blk_region);
+        hipLaunchKernelGGL(obs_quad_kernel, dim3((b->S.E + 15u) / 16u), dim3(256), quad_shm, st, b->S, b->T, b->C_dev, O, b->digest);
+    } else if (env_mask) {     // sparse by nature (the envs a VecEnv just reset): 64 envs' mask bytes per wavefront
         const uint32_t waves = (b->S.E + 63u) / 64u;
         hipLaunchKernelGGL(obs_scan_kernel, dim3((waves + 3u) / 4u), dim3(256), obs_shm, st, b->S, b->T, b->C_dev, O, b->digest);
     } else {

@@ -71,6 +71,9 @@ __device__ __forceinline__ ObsStage obs_stage_at(uint8_t* base, uint32_t n_nodes
     return s;
 }
 
+__device__ __forceinline__ void obs_env_masks(const StepCfg& C, const ObsIO& O, const uint32_t e, const uint32_t lane, const ObsStage& st,
+                                              const uint64_t (&own_ext)[4], const uint32_t n_disc, const uint32_t n_creds, const bool blank);
+
 // Structure: ALL loads first, then ALL stores.  On gfx9 loads and stores share the vmcnt counter and retire in order, so a
 // load issued after a store waits for that store's write acknowledgement; a first version that interleaved "load what this
 // field needs, store the field" per field spent most of a wavefront's ~25 us lifetime in such waits.  Now lane i fetches
@@ -101,7 +104,7 @@ __device__ __forceinline__ void obs_env(const DevState& S, const Topo& T, const 
     const uint16_t* cl = reinterpret_cast<const uint16_t*>(body + S.off_cred);
     const mcbs_node_static* NS = reinterpret_cast<const mcbs_node_static*>(T.base + C.off_node);
     const mcbs_triple* TR = reinterpret_cast<const mcbs_triple*>(T.base + C.off_triple);
-    const uint32_t Nm = O.Nmax, NP = C.n_props, L = C.L;
+    const uint32_t Nm = O.Nmax, NP = C.n_props;
 
     // ---------------- loads ----------------
     // (the list heads were fetched with the header, before the counts were known: see the top of this function)
@@ -193,6 +196,16 @@ __device__ __forceinline__ void obs_env(const DevState& S, const Topo& T, const 
             for (uint32_t i = lane; i < Nm; i += 64u) out[i] = (!blank && i < n_disc) ? (int32_t)st.priv[i] : 0;
         }
     }
+    obs_env_masks(C, O, e, lane, st, own_ext, n_disc, n_creds, blank);
+}
+
+// The mask fields of ONE env by one wavefront (e wave-uniform): mask_local and, for small action spaces, the fused big masks.  Reads
+// st.lmask (local-vulnerability mask by external index) and uses st.onb / st.pat / st.blk as scratch; own_ext bit i: the node at
+// external index i is an owned source (meaningful below n_disc).  Called by obs_env (a wavefront per env) and by obs_quad_kernel
+// (four envs staged by 16-lane groups, then streamed one after the other by the whole wavefront).
+__device__ __forceinline__ void obs_env_masks(const StepCfg& C, const ObsIO& O, const uint32_t e, const uint32_t lane, const ObsStage& st,
+                                              const uint64_t (&own_ext)[4], const uint32_t n_disc, const uint32_t n_creds, const bool blank) {
+    const uint32_t Nm = O.Nmax, L = C.L;
     if (O.mask_local) {
         int8_t* out = O.mask_local + (size_t)e * Nm * L;
         for (uint32_t idx = lane; idx < Nm * L; idx += 64u) {
@@ -586,14 +599,16 @@ __device__ __forceinline__ void obs_env(const DevState& S, const Topo& T, const 
 struct TinyStage { uint64_t props[16]; uint8_t priv[16], ext_of[16], cred_ext[16], cred_port[16]; };   // 192 bytes per env
 static_assert(sizeof(TinyStage) == 192, "tiny stage");
 
-__global__ __launch_bounds__(256) void obs_tiny_kernel(DevState S, Topo T, const StepCfg* __restrict__ Cp, ObsIO O, ObsDigest* digest) {
-    const StepCfg& C = *Cp;
-    __shared__ TinyStage stage[16];
-    const uint32_t grp = threadIdx.x >> 4, j = threadIdx.x & 15u, lane = threadIdx.x & 63u;
-    const uint32_t e = blockIdx.x * 16u + grp;
+struct TinyOut { uint32_t own16, n_disc, n_creds; bool blank, live; };   // per lane: what its env's mask fields need (obs_quad_kernel)
+
+// The small fields of the env of one 16-lane group (j = lane in the group, st = the group's staging area).  LMASK: also leave the
+// local-vulnerability mask of the node at external index j in lmask[j] (the mask fields' input).  Every lane of the wavefront runs to
+// the end (wave-level operations inside; obs_quad_kernel goes on with the masks).
+template <bool LMASK>
+__device__ __forceinline__ TinyOut obs_tiny_group(const DevState& S, const Topo& T, const StepCfg& C, const ObsIO& O, ObsDigest* digest, const uint32_t e,
+                                                  const uint32_t j, const uint32_t lane, TinyStage& st, uint32_t* lmask) {
     const bool valid = e < S.E;
     const uint32_t ec = valid ? e : 0u;
-    TinyStage& st = stage[grp];
     const uint8_t* body = S.body + (size_t)ec * S.body_stride;
     const uint32_t n_trip_cap = T.H().n_triples;
     // level 1
@@ -610,6 +625,7 @@ __global__ __launch_bounds__(256) void obs_tiny_kernel(DevState S, Topo T, const
     const mcbs_triple* TR = reinterpret_cast<const mcbs_triple*>(T.base + C.off_triple);
     const bool is_node = j < n_disc, is_cred = j < n_creds;
     const uint64_t props = S.row_get(body, n).props_tags & ROW_PROPS_MASK;
+    if constexpr (LMASK) lmask[j] = is_node ? local_mask_of(C, reinterpret_cast<const mcbs_node_static*>(T.base + C.off_node), body, n) : 0u;
     const mcbs_triple tr = TR[is_cred ? tid : 0u];
     const bool own = is_node && ((w_inst >> n) & 1ull);
     const uint32_t own16 = (uint32_t)(__ballot(own) >> (lane & 48u)) & 0xFFFFu;      // this env's owned-source bits by external index
@@ -623,7 +639,9 @@ __global__ __launch_bounds__(256) void obs_tiny_kernel(DevState S, Topo T, const
     if (is_cred) { st.cred_ext[j] = st.ext_of[tr.node & 15u]; st.cred_port[j] = (uint8_t)tr.port; }
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
-    if (!live) return;                                         // (after the wave-level operations: the four envs of a wavefront differ)
+    TinyOut res;
+    res.own16 = own16; res.n_disc = n_disc; res.n_creds = n_creds; res.blank = blank; res.live = live;
+    if (!live) return res;                                     // (after the wave-level operations: the four envs of a wavefront differ)
     // ---------------- stores ----------------
     if (j == 0) {
         ObsDigest d;
@@ -705,7 +723,49 @@ __global__ __launch_bounds__(256) void obs_tiny_kernel(DevState S, Topo T, const
         }
     }
     if (O.priv && j < Nm) O.priv[(size_t)e * Nm + j] = (!blank && j < n_disc) ? (int32_t)st.priv[j] : 0;
+    return res;
 }
+
+__global__ __launch_bounds__(256) void obs_tiny_kernel(DevState S, Topo T, const StepCfg* __restrict__ Cp, ObsIO O, ObsDigest* digest) {
+    const StepCfg& C = *Cp;
+    __shared__ TinyStage stage[16];
+    const uint32_t grp = threadIdx.x >> 4, j = threadIdx.x & 15u, lane = threadIdx.x & 63u;
+    obs_tiny_group<false>(S, T, C, O, digest, blockIdx.x * 16u + grp, j, lane, stage[grp], nullptr);
+}
+
+// Small topologies WITH mask fields: the small fields as in obs_tiny_kernel — four envs per wavefront, sixteen lanes each, so the loads
+// and the dozen small set-up jobs of an env are paid once per FOUR envs —, then the whole wavefront streams the mask fields of its four
+// envs one after the other (obs_env_masks, the same writers as a wavefront per env).  obs_small_kernel spent ~1 250 vector instructions
+// per 12-15 KB env, half of them in per-env set-up that kept 16 of 64 lanes busy, and was bound by instruction issue, not by HBM
+// (profiles/round3_notes.md section 7).
+__global__ __launch_bounds__(256) void obs_quad_kernel(DevState S, Topo T, const StepCfg* __restrict__ Cp, ObsIO O, ObsDigest* digest) {
+    const StepCfg& C = *Cp;
+    extern __shared__ uint4 obs_lds[];                         // per wavefront: onb [272] | pat [1 040] | blk [16 x blk_region]
+    __shared__ TinyStage stage[16];
+    __shared__ uint32_t lmask[16][16];
+    const uint32_t grp = threadIdx.x >> 4, j = threadIdx.x & 15u, lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const TinyOut r = obs_tiny_group<true>(S, T, C, O, digest, blockIdx.x * 16u + grp, j, lane, stage[grp], lmask[grp]);
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    uint8_t* scratch = reinterpret_cast<uint8_t*>(obs_lds) + wave * (272u + 1040u + 16u * O.blk_region);
+    ObsStage st{};
+    st.onb = scratch; st.pat = reinterpret_cast<uint4*>(scratch + 272u); st.blk = reinterpret_cast<uint32_t*>(scratch + 272u + 1040u);
+    const uint32_t packed = r.own16 | (r.n_disc << 16) | (r.n_creds << 21) | ((uint32_t)r.blank << 26) | ((uint32_t)r.live << 27);   // counts <= 16
+#pragma unroll 1
+    for (uint32_t g = 0; g < 4u; ++g) {
+        const uint32_t d = __builtin_amdgcn_readlane(packed, g * 16u);      // env g of this wavefront, as scalars
+        if (!((d >> 27) & 1u)) continue;                                    // past the batch, or a skip action: the previous observation stands
+        const uint64_t own_ext[4] = {(uint64_t)(d & 0xFFFFu), 0ull, 0ull, 0ull};
+        st.lmask = lmask[wave * 4u + g];
+        // (the writers' per-lane set-up is recomputed per env on purpose: hoisted out of this loop it held 147 VGPRs, three wavefronts per SIMD)
+        uint32_t lane_g = lane;
+        asm volatile("" : "+v"(lane_g));
+        obs_env_masks(C, O, blockIdx.x * 16u + wave * 4u + g, lane_g, st, own_ext, (d >> 16) & 31u, (d >> 21) & 31u, ((d >> 26) & 1u) != 0u);
+        __builtin_amdgcn_wave_barrier();                                    // the next env reuses the scratch area
+    }
+}
+
 
 // One wavefront per env (every env, or the env's byte in env_mask decides: callers with sparse masks use obs_scan_kernel instead).
 __global__ __launch_bounds__(256) void obs_small_kernel(DevState S, Topo T, const StepCfg* __restrict__ Cp, ObsIO O, ObsDigest* digest) {

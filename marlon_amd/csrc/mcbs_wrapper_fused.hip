@@ -300,7 +300,7 @@ struct FusedHook {
     // dword idx of field f (1..4) of the env whose LDS record is st — the same values one at a time, for rows that are not whole vectors
     template <uint32_t f>
     __device__ __forceinline__ uint32_t dword_value(const FusedStage& st, uint32_t idx) const {
-        const uint32_t meta = st.meta(), n_disc = meta & 0xFFu, n_creds = (meta >> 8) & 0xFFu;
+        const uint32_t meta = st.meta(), n_creds = (meta >> 8) & 0xFFu;
         const bool blank = meta & FM_BLANK;
         if (f == 3) {
             if (blank) return 2u;

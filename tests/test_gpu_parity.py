@@ -193,6 +193,59 @@ def test_observations_match_oracle_batched(trace):
     eng.close()
 
 
+@pytest.mark.parametrize("trace", ["toyctf_defender_s11", "chain10_mix_s3", "chain4_defender_s21"])
+def test_quad_observation_kernel_equals_wavefront_per_env_and_oracle(trace, monkeypatch):
+    """Observations of small topologies WITH mask fields have two writers: obs_quad_kernel (four envs per wavefront: small fields by
+    16-lane groups, then the masks env after env; the default where mask rows are not whole cache lines, MCBS_QUAD_OBS=1 everywhere)
+    and obs_small_kernel (a wavefront per env; MCBS_NO_QUAD_OBS=1).  Both against the oracle, every field of every step, on a batch
+    that fills neither its last workgroup nor its last wavefront, with out-of-range actions (blank observations) in the mix, dense
+    and line-padded mask_discrete rows, into buffers pre-filled with a sentinel (cyberbattle_env.py:643-677,753-773,859-933)."""
+    from marlon_amd._abi import RNG_PHILOX
+    from oracle.oracle import Oracle
+    _, sj = parity.load_trace(trace)
+    topo = parity.topology_for(trace)
+    E = 515
+    spec = parity.spec_from_json(sj, n_envs=E, auto_reset=True, rng_kind=RNG_PHILOX, seed=31, max_episode_steps=45)
+    monkeypatch.setenv("MCBS_QUAD_OBS", "1")
+    quad = _engine().BatchEngine(topo, spec)
+    monkeypatch.delenv("MCBS_QUAD_OBS")
+    monkeypatch.setenv("MCBS_NO_QUAD_OBS", "1")
+    wave = _engine().BatchEngine(topo, spec)
+    monkeypatch.delenv("MCBS_NO_QUAD_OBS")
+    orc = Oracle(topo, spec)
+    fields = [f for f in parity.OBS_FIELDS]
+    A = quad.discrete_action_count()
+    pad = (A + 127) // 128 * 128
+    blanks = 0
+    for t in range(100):
+        if t == 50:                                            # second half: mask_discrete rows padded to whole 128-byte lines
+            quad.set_mask_discrete_stride(pad)
+            wave.set_mask_discrete_stride(pad)
+        a = quad.sample_actions(t % 3 != 0, seed=13, step=t)
+        if t % 7 == 2:
+            a[::3, 1] = spec.maximum_node_count + 1            # beyond the discovered nodes: out of bound, the blank observation
+        oq, ow = quad.alloc_obs(fields + ["mask_discrete"]), wave.alloc_obs(fields + ["mask_discrete"])
+        for o in (oq, ow):
+            for v in o.values():
+                v.fill_(5)
+        quad.step_observe(a, oq)
+        wave.step_observe(a, ow)
+        oo = orc.alloc_obs(fields)
+        out = orc.step(a.cpu().numpy(), obs=oo)
+        blanks += int(out["oob"].sum())
+        for f in fields:
+            np.testing.assert_array_equal(oq[f].cpu().numpy(), oo[f], err_msg=f"{trace} step {t} {f}: quad kernel vs oracle")
+            np.testing.assert_array_equal(ow[f].cpu().numpy(), oo[f], err_msg=f"{trace} step {t} {f}: wavefront per env vs oracle")
+        disc = np.concatenate([oo["mask_connect"].reshape(E, -1), oo["mask_local"].reshape(E, -1), oo["mask_remote"].reshape(E, -1)], axis=1)
+        for name, o in (("quad", oq), ("wave", ow)):
+            m = o["mask_discrete"].cpu().numpy()
+            np.testing.assert_array_equal(m[:, :A], disc, err_msg=f"{trace} step {t} mask_discrete ({name})")
+            assert (m[:, A:] == 5).all(), f"{trace} step {t}: {name} wrote into the padding"
+    assert blanks > 50
+    quad.close()
+    wave.close()
+
+
 @pytest.mark.parametrize("n_nodes,seed", [(3, 1), (9, 2), (16, 3), (17, 4), (33, 5), (64, 6), (65, 7), (96, 11), (128, 8), (129, 9), (200, 10), (255, 12)])
 def test_random_topologies_engine_vs_oracle(n_nodes, seed):
     """The config-5 generator at sizes on both sides of every layout boundary (packed / general at 16 nodes, 1 / 2 / 4 words
