@@ -806,8 +806,11 @@ static int launch_obs_inner(mcbs_batch* b, const mcbs_obs_buffers* o, hipStream_
     // store instead of four partial lines); Chain-10, whose mask rows are whole 128-byte lines written with non-temporal stores, streams
     // ~10 % FASTER with a wavefront per env (152-168 against 171-185 us at 65 536 envs) and keeps it.  MCBS_QUAD_OBS=1 / MCBS_NO_QUAD_OBS=1
     // force one or the other.
+    // The flat Discrete mask of a batch too small to give every SIMD several four-env wavefronts also stays (ToyCtf, 16 384 envs: 50 us
+    // against 52-54; 65 536 envs: 207 -> 171 us).
     const bool line_rows = (o->mask_connect && O.nt_connect) || (o->mask_discrete && O.nt_discrete);
-    if (groups_ok && !b->no_quad_obs && (!line_rows || b->force_quad_obs)) {
+    const bool few_waves = o->mask_discrete && b->S.E < 32768u;
+    if (groups_ok && !b->no_quad_obs && ((!line_rows && !few_waves) || b->force_quad_obs)) {
         const uint32_t quad_shm = 4u * (272u + 1040u + 16u * O.blk_region);
         hipLaunchKernelGGL(obs_quad_kernel, dim3((b->S.E + 15u) / 16u), dim3(256), quad_shm, st, b->S, b->T, b->C_dev, O, b->digest);
     } else if (env_mask) {     // sparse by nature (the envs a VecEnv just reset): 64 envs' mask bytes per wavefront
