@@ -246,6 +246,57 @@ def test_quad_observation_kernel_equals_wavefront_per_env_and_oracle(trace, monk
     wave.close()
 
 
+@pytest.mark.parametrize("trace", ["toyctf_defender_s11", "chain4_defender_s21", "tiny_defender_s62", "sink_defender_s43"])
+def test_observation_writers_over_observation_bounds(trace, monkeypatch):
+    """The mask writers pick their shape from divisibility: connect rows of P*Cmax bytes that are / are not multiples of 16 or 4, per-source
+    blocks of Nmax*P*Cmax bytes, masks whose length is / is not a whole number of 16-byte chunks, env bases at every 4-byte phase.  The
+    same topology under a spread of (maximum_node_count, maximum_total_credentials) bounds — the observation's shape, not the
+    simulation's — through both observation kernels (four envs per wavefront; a wavefront per env; beyond 16 nodes the region kernels),
+    every field and the flat Discrete mask against the oracle (cyberbattle_env.py:643-677, action_masking.py:96-110)."""
+    from marlon_amd._abi import RNG_PHILOX
+    from oracle.oracle import Oracle
+    _, sj = parity.load_trace(trace)
+    topo = parity.topology_for(trace)
+    n, c = int(topo.n_nodes), max(1, len(topo.triples))
+    E = 67
+    fields = [f for f in parity.OBS_FIELDS]
+    tried = set()
+    for nm, cm in ((n, c), (n + 1, c + 1), (n + 2, c + 3), (13, 7), (15, 9), (16, 16), (16, 5), (11, 11), (12, 6), (14, 10), (20, c + 2)):
+        nm, cm = max(nm, n), max(cm, c)
+        if (nm, cm) in tried:
+            continue
+        tried.add((nm, cm))
+        spec = parity.spec_from_json(sj, n_envs=E, auto_reset=True, rng_kind=RNG_PHILOX, seed=77, max_episode_steps=30,
+                                     maximum_node_count=nm, maximum_total_credentials=cm)
+        monkeypatch.setenv("MCBS_QUAD_OBS", "1")
+        quad = _engine().BatchEngine(topo, spec)
+        monkeypatch.delenv("MCBS_QUAD_OBS")
+        monkeypatch.setenv("MCBS_NO_QUAD_OBS", "1")
+        wave = _engine().BatchEngine(topo, spec)
+        monkeypatch.delenv("MCBS_NO_QUAD_OBS")
+        orc = Oracle(topo, spec)
+        A = quad.discrete_action_count()
+        for t in range(24):
+            a = quad.sample_actions(t % 4 != 3, seed=5, step=t)
+            if t % 5 == 1:
+                a[::4, 1] = nm + 2                             # out of bound: the blank observation
+            oq, ow = quad.alloc_obs(fields + ["mask_discrete"]), wave.alloc_obs(fields + ["mask_discrete"])
+            quad.step_observe(a, oq)
+            wave.step_observe(a, ow)
+            oo = orc.alloc_obs(fields)
+            orc.step(a.cpu().numpy(), obs=oo)
+            ctx = f"{trace} bounds ({nm}, {cm}) step {t}"
+            disc = np.concatenate([oo["mask_connect"].reshape(E, -1), oo["mask_local"].reshape(E, -1), oo["mask_remote"].reshape(E, -1)], axis=1)
+            assert disc.shape[1] == A
+            for name, o in (("four envs per wavefront", oq), ("wavefront per env", ow)):
+                for f in fields:
+                    np.testing.assert_array_equal(o[f].cpu().numpy(), oo[f], err_msg=f"{ctx} {f} ({name})")
+                np.testing.assert_array_equal(o["mask_discrete"].cpu().numpy(), disc, err_msg=f"{ctx} mask_discrete ({name})")
+        quad.close()
+        wave.close()
+    assert len(tried) >= 8
+
+
 @pytest.mark.parametrize("n_nodes,seed", [(3, 1), (9, 2), (16, 3), (17, 4), (33, 5), (64, 6), (65, 7), (96, 11), (128, 8), (129, 9), (200, 10), (255, 12)])
 def test_random_topologies_engine_vs_oracle(n_nodes, seed):
     """The config-5 generator at sizes on both sides of every layout boundary (packed / general at 16 nodes, 1 / 2 / 4 words
