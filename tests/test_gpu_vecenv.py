@@ -563,6 +563,61 @@ def test_one_launch_wrapper_step_equals_three_launches(case, monkeypatch):
         env.close()
 
 
+@pytest.mark.parametrize("topology", ["chain4", "toyctf", "tiny"])
+def test_one_launch_wrapper_step_over_observation_bounds(topology, monkeypatch):
+    """The one-launch wrapper step streams the observation's rows as 16-byte vectors where a row is whole vectors and as dwords where it
+    is not, from LDS records sized by the bounds.  The same topology under a spread of (maximum_node_count, maximum_total_credentials)
+    — rows of 3 .. 16 privilege dwords, 1 .. 16 cache rows, property rows of every phase — against the three-launch step and the
+    mask-writing wrapper: outputs, observation, terminal observation, counters, digests (attack_wrapper.py:255-372,474-522)."""
+    import torch
+    from marlon_amd.samples import chainpattern, tinytoy, toy_ctf
+    from marlon_amd.wrappers import AttackerVecEnv
+    make = {"chain4": lambda: chainpattern.new_environment(4), "toyctf": toy_ctf.new_environment, "tiny": tinytoy.new_environment}[topology]
+    n, c = {"chain4": (6, 5), "toyctf": (10, 5), "tiny": (3, 1)}[topology]
+    E, T = 203, 12
+    tried = set()
+    for nm, cm in ((n, c), (n + 1, c + 1), (n + 2, c + 4), (9, 7), (11, 3), (13, 11), (14, 6), (15, 13), (16, 16), (16, c), (n, 16)):
+        nm, cm = max(nm, n), max(cm, c)
+        if (nm, cm) in tried:
+            continue
+        tried.add((nm, cm))
+        kw = dict(maximum_node_count=nm, maximum_total_credentials=cm, discrete=True, max_timesteps=T)
+        ref = AttackerVecEnv(make(), E, **kw)
+        fused = AttackerVecEnv(make(), E, materialize_masks=False, **kw)
+        assert fused.engine.wrapper_step_launches(False) == 1, f"{topology} ({nm}, {cm}): not the one-launch step"
+        monkeypatch.setenv("MCBS_NO_FUSED_WRAPPER", "1")
+        three = AttackerVecEnv(make(), E, materialize_masks=False, **kw)
+        monkeypatch.delenv("MCBS_NO_FUSED_WRAPPER")
+        dev = ref.engine.device
+        g = torch.Generator(device=dev).manual_seed(nm * 31 + cm)
+        for t in range(30):
+            m = ref.action_masks()
+            scores = torch.rand(m.shape, generator=g, device=dev)
+            a = torch.where(m, scores, torch.full_like(scores, -1.0)).argmax(dim=1)
+            if t % 5 == 2 or (t + 1) % T == 0:
+                a[::7] = ref.discrete_n - 1                      # intercepted (undiscovered node index) unless everything is discovered
+            (o1, r1, te1, tr1, i1), (o2, r2, te2, tr2, i2) = [env.step(a.clone()) for env in (fused, three)]
+            r_ref = ref.step(a)
+            ctx = f"{topology} bounds ({nm}, {cm}) step {t}"
+            assert torch.equal(r1, r2) and torch.equal(te1, te2) and torch.equal(tr1, tr2), ctx + " rewards / flags"
+            assert torch.equal(r1, r_ref[1]) and torch.equal(te1, r_ref[2]) and torch.equal(tr1, r_ref[3]), ctx + " vs the mask-writing wrapper"
+            for k in i1:
+                assert torch.equal(i1[k], i2[k]), f"{ctx} info {k}"
+            for k in o1:
+                assert torch.equal(o1[k], o2[k]), f"{ctx} observation {k}"
+                assert torch.equal(o1[k], r_ref[0][k]), f"{ctx} observation {k} vs the mask-writing wrapper"
+            for k, x in fused.terminal_observation.items():
+                assert torch.equal(x, three.terminal_observation[k]), f"{ctx} terminal observation {k}"
+                assert torch.equal(x, ref.terminal_observation[k]), f"{ctx} terminal observation {k} vs the mask-writing wrapper"
+            for k in ("timesteps", "valid_action_count", "invalid_action_count", "episode_returns", "last_cyber_reward", "has_cyber_reward"):
+                assert torch.equal(getattr(fused, k), getattr(three, k)), f"{ctx} wrapper counter {k}"
+            logits = torch.rand((E, fused.discrete_n), generator=g, device=dev)
+            assert torch.equal(fused.mask_logits(logits.clone(), -1.0), three.mask_logits(logits.clone(), -1.0)), ctx + " mask_logits (digests)"
+        for env in (ref, fused, three):
+            env.close()
+    assert len(tried) >= 8
+
+
 def test_terminal_observation_of_an_intercepted_last_action_is_the_one_that_stands(monkeypatch):
     """An action with an undiscovered node index does not step the env and returns the observation the env already had
     (attack_wrapper.py:286-308) — also when that very step truncates the episode: the terminal observation is then that standing
