@@ -1,0 +1,79 @@
+"""More golden traces from the UNMODIFIED reference: observation bounds other than the tight ones, and Chain-10 with a defender.
+
+Run in the build container only (needs /root/reference):   python oracle/refharness/gen_golden_bounds.py
+Writes NEW files under tests/golden/ only (the traces gen_golden.py wrote stay byte-identical); same harness (gen_golden.run_trace),
+same record layout, picked up by tests/parity.trace_names() like the others.
+
+Why: the observation's SHAPE is set by `maximum_node_count` / `maximum_total_credentials` (cyberbattle_env.py:416-470), and the mask
+writers of this build branch on the divisibility of those shapes (16-byte chunks, per-source blocks, padded rows).  The first batch
+of traces pinned the tight bounds (Chain-10 @ 12/12, ToyCtf @ 12/10, Chain-4 @ 6/6); these pin loose and odd ones against the
+reference itself, not only against the oracle: Chain-10 @ 14/16 and 13/13, ToyCtf @ 16/16 and 11/7, Chain-4 @ 9/7 — and Chain-10 with
+ScanAndReimage + an SLA constraint (the reference's own defender on the headline topology).
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+import gen_golden as G  # noqa: E402  (imports the reference through ref_loader at module level)
+
+ref = G.ref
+F = G.F
+
+
+def main():
+    AG, DC = ref.env.AttackerGoal, ref.env.DefenderConstraint
+    SAR = ref.defender.ScanAndReimageCompromisedMachines
+    chain10, chain4, toyctf = (F.flatten(ref.chainpattern.new_environment(10)), F.flatten(ref.chainpattern.new_environment(4)),
+                               F.flatten(ref.toy_ctf.new_environment()))
+
+    def goal(**kw):
+        g = dict(reward=0.0, low_availability=1.0, own_atleast=0, own_atleast_percent=1.0)
+        g.update(kw)
+        return g
+
+    def spec(nm, cm, **kw):
+        d = dict(maximum_node_count=nm, maximum_total_credentials=cm, maximum_discoverable_credentials_per_action=5, attacker_goal=goal(),
+                 winning_reward=5000.0, losing_reward=0.0, maintain_sla=0.0, defender=None)
+        d.update(kw)
+        return d
+
+    # ---- Chain-10, attacker only, loose / odd bounds ----
+    for nm, cm, seed, policy in ((14, 16, 91, "mix"), (13, 13, 92, "valid")):
+        def make(nm=nm, cm=cm):
+            return ref.CyberBattleChain(size=10, attacker_goal=AG(own_atleast_percent=1.0), maximum_node_count=nm,
+                                        maximum_total_credentials=cm, throws_on_invalid_actions=False)
+        G.run_trace(f"chain10_bounds{nm}x{cm}_s{seed}", make, chain10, 300, policy, seed, spec(nm, cm))
+
+    # ---- Chain-10 + ScanAndReimage(0.5, 3, 3), SLA 0.5: the reference's defender on the headline topology ----
+    sp_d = spec(12, 12, defender=["scan_and_reimage", 0.5, 3, 3], maintain_sla=0.5, losing_reward=-1000.0)
+
+    def chain10_def():
+        return ref.CyberBattleChain(size=10, attacker_goal=AG(own_atleast_percent=1.0), defender_agent=SAR(0.5, 3, 3),
+                                    defender_constraint=DC(maintain_sla=0.5), losing_reward=-1000.0, maximum_node_count=12,
+                                    maximum_total_credentials=12, throws_on_invalid_actions=False)
+    G.run_trace("chain10_defender_s93", chain10_def, chain10, 400, "mix", 93, sp_d, tape_dps=6)
+
+    # ---- ToyCtf + ScanAndReimage(0.6, 2, 5), loose / odd bounds ----
+    for nm, cm, seed in ((16, 16, 94), (11, 7, 95)):
+        sp_t = spec(nm, cm, attacker_goal=goal(own_atleast=6), maintain_sla=0.80, defender=["scan_and_reimage", 0.6, 2, 5])
+
+        def make(nm=nm, cm=cm):
+            return ref.CyberBattleToyCtf(attacker_goal=AG(own_atleast=6), defender_agent=SAR(0.6, 2, 5), defender_constraint=DC(maintain_sla=0.80),
+                                         maximum_node_count=nm, maximum_total_credentials=cm, throws_on_invalid_actions=False)
+        G.run_trace(f"toyctf_bounds{nm}x{cm}_s{seed}", make, toyctf, 300, "mix", seed, sp_t, tape_dps=4)
+
+    # ---- Chain-4 + ScanAndReimage(1.0, 1, 1) @ 9/7 ----
+    sp_c4 = spec(9, 7, defender=["scan_and_reimage", 1.0, 1, 1])
+
+    def chain4_def():
+        return ref.CyberBattleChain(size=4, attacker_goal=AG(own_atleast_percent=1.0), defender_agent=SAR(1.0, 1, 1), maximum_node_count=9,
+                                    maximum_total_credentials=7, throws_on_invalid_actions=False)
+    G.run_trace("chain4_bounds9x7_s96", chain4_def, chain4, 250, "mix", 96, sp_c4, tape_dps=2)
+
+
+if __name__ == "__main__":
+    main()
