@@ -8,7 +8,8 @@ Why: the observation's SHAPE is set by `maximum_node_count` / `maximum_total_cre
 writers of this build branch on the divisibility of those shapes (16-byte chunks, per-source blocks, padded rows).  The first batch
 of traces pinned the tight bounds (Chain-10 @ 12/12, ToyCtf @ 12/10, Chain-4 @ 6/6); these pin loose and odd ones against the
 reference itself, not only against the oracle: Chain-10 @ 14/16 and 13/13, ToyCtf @ 16/16 and 11/7, Chain-4 @ 9/7 — and Chain-10 with
-ScanAndReimage + an SLA constraint (the reference's own defender on the headline topology).
+ScanAndReimage + an SLA constraint (the reference's own defender on the headline topology); and three traces of marlon's attacker
+wrappers at such bounds (gen_golden_wrappers.run).
 """
 from __future__ import annotations
 
@@ -73,6 +74,22 @@ def main():
         return ref.CyberBattleChain(size=4, attacker_goal=AG(own_atleast_percent=1.0), defender_agent=SAR(1.0, 1, 1), maximum_node_count=9,
                                     maximum_total_credentials=7, throws_on_invalid_actions=False)
     G.run_trace("chain4_bounds9x7_s96", chain4_def, chain4, 250, "mix", 96, sp_c4, tape_dps=2)
+
+    # ---- marlon's attacker wrappers over the reference env at such bounds (rows of the flat observation that are not whole 16-byte
+    # vectors; a Discrete space of another size): same recorder as gen_golden_wrappers.py ----
+    import gen_golden_wrappers as W
+    W.run("wrap_chain4_discrete_b9x7_s97", chain4_def, sp_c4, 260, 97, True, 40, 2)
+    sp_t = spec(11, 7, attacker_goal=goal(own_atleast=6), maintain_sla=0.80, defender=["scan_and_reimage", 0.6, 2, 5])
+
+    def toyctf_11x7():
+        return ref.CyberBattleToyCtf(attacker_goal=AG(own_atleast=6), defender_agent=SAR(0.6, 2, 5), defender_constraint=DC(maintain_sla=0.80),
+                                     maximum_node_count=11, maximum_total_credentials=7, throws_on_invalid_actions=False)
+    W.run("wrap_toyctf_md_b11x7_s98", toyctf_11x7, sp_t, 260, 98, False, 60, 4)
+
+    def chain10_14x16():
+        return ref.CyberBattleChain(size=10, attacker_goal=AG(own_atleast_percent=1.0), maximum_node_count=14, maximum_total_credentials=16,
+                                    throws_on_invalid_actions=False)
+    W.run("wrap_chain10_discrete_b14x16_s99", chain10_14x16, spec(14, 16), 260, 99, True, 70, 0)
 
 
 if __name__ == "__main__":

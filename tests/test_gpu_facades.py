@@ -128,7 +128,9 @@ def test_gym_facade_errors_and_helpers():
     env.close()
 
 
-WRAP = ["wrap_toyctf_md_s61", "wrap_toyctf_discrete_s62", "wrap_chain10_md_s63", "wrap_chain10_discrete_s64"]
+WRAP = ["wrap_toyctf_md_s61", "wrap_toyctf_discrete_s62", "wrap_chain10_md_s63", "wrap_chain10_discrete_s64",
+        # round 3 (oracle/refharness/gen_golden_bounds.py): observation bounds other than the tight ones — Chain-4 @ 9/7, ToyCtf @ 11/7, Chain-10 @ 14/16
+        "wrap_chain4_discrete_b9x7_s97", "wrap_toyctf_md_b11x7_s98", "wrap_chain10_discrete_b14x16_s99"]
 FLAT = {"leaked_credentials": "leaked_credentials", "credential_cache_matrix": "credential_cache_matrix",
         "discovered_nodes_properties": "discovered_nodes_properties", "nodes_privilegelevel": "nodes_privilegelevel",
         "local_vulnerability": "local_vulnerability", "remote_vulnerability": "remote_vulnerability", "connect": "connect"}
@@ -151,7 +153,7 @@ def test_attacker_vec_env_matches_marlon_wrappers(name):
     from marlon_amd.wrappers import AttackerVecEnv
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     sj = json.loads(bytes(z["spec_json"]).decode())
-    topo = parity.topology_for("toyctf" if "toyctf" in name else "chain10")
+    topo = parity.topology_for(name[len("wrap_"):])
     d = sj["defender"]
     env = AttackerVecEnv(topo, 1, maximum_node_count=sj["maximum_node_count"], maximum_total_credentials=sj["maximum_total_credentials"],
                          attacker_goal=ce.AttackerGoal(**sj["attacker_goal"]), defender_constraint=ce.DefenderConstraint(sj["maintain_sla"]),

@@ -31,7 +31,7 @@ def _make(name, n_envs=1, **extra):
     from marlon_amd.wrappers import AttackerVecEnv
     z = np.load(os.path.join(parity.GOLDEN, name + ".npz"))
     sj = json.loads(bytes(z["spec_json"]).decode())
-    topo = parity.topology_for("toyctf" if "toyctf" in name else "chain10")
+    topo = parity.topology_for(name[len("wrap_"):])
     d = sj["defender"]
     att = AttackerVecEnv(topo, n_envs, maximum_node_count=sj["maximum_node_count"], maximum_total_credentials=sj["maximum_total_credentials"],
                          attacker_goal=ce.AttackerGoal(**sj["attacker_goal"]), defender_constraint=ce.DefenderConstraint(sj["maintain_sla"]),
