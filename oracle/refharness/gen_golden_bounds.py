@@ -9,7 +9,7 @@ writers of this build branch on the divisibility of those shapes (16-byte chunks
 of traces pinned the tight bounds (Chain-10 @ 12/12, ToyCtf @ 12/10, Chain-4 @ 6/6); these pin loose and odd ones against the
 reference itself, not only against the oracle: Chain-10 @ 14/16 and 13/13, ToyCtf @ 16/16 and 11/7, Chain-4 @ 9/7 — and Chain-10 with
 ScanAndReimage + an SLA constraint (the reference's own defender on the headline topology); and three traces of marlon's attacker
-wrappers at such bounds (gen_golden_wrappers.run).
+wrappers at such bounds (gen_golden_wrappers.run); and the config-5 generator at 100 and 200 nodes (more than one 64-bit word per node set).
 """
 from __future__ import annotations
 
@@ -90,6 +90,20 @@ def main():
         return ref.CyberBattleChain(size=10, attacker_goal=AG(own_atleast_percent=1.0), maximum_node_count=14, maximum_total_credentials=16,
                                     throws_on_invalid_actions=False)
     W.run("wrap_chain10_discrete_b14x16_s99", chain10_14x16, spec(14, 16), 260, 99, True, 70, 0)
+
+    # ---- the config-5 generator at sizes that take this build's G-lanes-per-env kernel (two words per set at 100 nodes, four at 200),
+    # stepped by the reference itself; masks kept as CRC32 only ----
+    from marlon_amd.samples import random_net
+    for n, seed, steps in ((100, 52, 220), (200, 53, 160)):
+        topo = F.flatten(random_net.build(ref.model, n, 7))
+        n_cred = max(1, len(topo.triples))
+        sp = spec(n, n_cred, defender=["scan_and_reimage", 0.5, 3, 4], maintain_sla=0.5)
+
+        def make(n=n, n_cred=n_cred):
+            return ref.env.CyberBattleEnv(random_net.build(ref.model, n, 7), attacker_goal=AG(own_atleast_percent=1.0), defender_agent=SAR(0.5, 3, 4),
+                                          defender_constraint=DC(maintain_sla=0.5), maximum_node_count=n, maximum_total_credentials=n_cred,
+                                          throws_on_invalid_actions=False)
+        G.run_trace(f"random{n}_defender_s{seed}", make, topo, steps, "mix", seed, sp, tape_dps=6, store_masks=False)
 
 
 if __name__ == "__main__":

@@ -46,6 +46,8 @@ def topology_for(trace_name: str) -> F.FlatTopology:
         return F.flatten(labelled_graph.build(model, int(trace_name.split("_")[1][1:]), 6))
     if trace_name.startswith("random24"):
         return F.flatten(random_net.build(model, 24, 7))
+    if trace_name.startswith("random100") or trace_name.startswith("random200"):
+        return F.flatten(random_net.build(model, int(trace_name[6:9]), 7))
     raise KeyError(trace_name)
 
 
