@@ -765,9 +765,17 @@ static int launch_obs_inner(mcbs_batch* b, const mcbs_obs_buffers* o, hipStream_
     // least one chunk and whole-chunk masks; MCBS_NO_BLOCK_MASKS=1: round 2's writers
     uint32_t blk_bytes = 0;
     const size_t BLc = (size_t)O.Nmax * RL, BLr = (size_t)O.Nmax * b->C.R;
+    // largest block whose four variants still fit a workgroup's LDS next to the staging areas (four wavefronts, 60 KB in all, 4 KB of it
+    // obs_quad_kernel's static arrays): 3 161 bytes for a 16-node topology, less when the credential lists are long
+    size_t blk_cap = 0;
+    {
+        const size_t fixed = obs_stage_bytes(b->S.N, b->topo->H()->n_triples, 0), budget = (61440u - 4096u) / 4u;
+        if (budget > fixed + 16u * 12u) blk_cap = ((budget - fixed) / 16u) * 4u - 31u;
+        if (blk_cap > 4064u) blk_cap = 4064u;
+    }
     if (!b->no_block_masks) {
-        if (O.fuse_connect == 3 && BLc % 4 == 0 && BLc >= 16 && BLc <= 4064) { O.fuse_connect = 4; blk_bytes = (uint32_t)BLc; }
-        if (O.fuse_remote && BLr % 4 == 0 && BLr >= 16 && BLr <= 4064 && MR % 16 == 0 && reinterpret_cast<uintptr_t>(o->mask_remote) % 16 == 0) {
+        if (O.fuse_connect == 3 && BLc % 4 == 0 && BLc >= 16 && BLc <= blk_cap) { O.fuse_connect = 4; blk_bytes = (uint32_t)BLc; }
+        if (O.fuse_remote && BLr % 4 == 0 && BLr >= 16 && BLr <= blk_cap && MR % 16 == 0 && reinterpret_cast<uintptr_t>(o->mask_remote) % 16 == 0) {
             O.fuse_remote = 2;
             if (BLr > blk_bytes) blk_bytes = (uint32_t)BLr;
         }
@@ -781,9 +789,9 @@ static int launch_obs_inner(mcbs_batch* b, const mcbs_obs_buffers* o, hipStream_
         if (O.fuse_discrete && stride % 4 != 0) O.fuse_discrete = 0;
         O.nt_discrete = (O.fuse_discrete && stride % 128 == 0 && reinterpret_cast<uintptr_t>(o->mask_discrete) % 128 == 0 && M % 128 == 0) ? 1u : 0u;
     }
-    O.disc_blocks = (!b->no_block_masks && O.fuse_discrete && RL % 16 != 0 && BLc % 4 == 0 && BLc >= 16 && BLc <= 4064) ? 1u : 0u;
+    O.disc_blocks = (!b->no_block_masks && O.fuse_discrete && RL % 16 != 0 && BLc % 4 == 0 && BLc >= 16 && BLc <= blk_cap) ? 1u : 0u;
     if (O.disc_blocks && BLc > blk_bytes) blk_bytes = (uint32_t)BLc;
-    O.disc_remote_blocks = (!b->no_block_masks && O.fuse_discrete && BLr % 4 == 0 && BLr >= 16 && BLr <= 4064) ? 1u : 0u;
+    O.disc_remote_blocks = (!b->no_block_masks && O.fuse_discrete && BLr % 4 == 0 && BLr >= 16 && BLr <= blk_cap) ? 1u : 0u;
     if (O.disc_remote_blocks && BLr > blk_bytes) blk_bytes = (uint32_t)BLr;
     O.blk_region = blk_bytes ? ((blk_bytes + 16u + 15u) / 16u) * 4u : 0u;
     O.dBLc = fast_div_host(BLc ? (uint32_t)BLc : 1u); O.dBLr = fast_div_host(BLr ? (uint32_t)BLr : 1u);

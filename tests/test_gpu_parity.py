@@ -297,6 +297,71 @@ def test_observation_writers_over_observation_bounds(trace, monkeypatch):
     assert len(tried) >= 8
 
 
+def _many_ports_environment(n_ports):
+    """Five nodes, `n_ports` ports: connect rows of n_ports * maximum_total_credentials bytes, the per-source block of the connect mask up
+    to the LDS budget of the observation kernels and beyond it."""
+    from marlon_amd import model as m
+    allow = m.RulePermission.ALLOW
+    ports = [f"P{i:02d}" for i in range(n_ports)]
+    fw = lambda: m.FirewallConfiguration(incoming=[m.FirewallRule(p, allow) for p in ports], outgoing=[m.FirewallRule(p, allow) for p in ports])
+    vuln = lambda kind, outcome: m.VulnerabilityInfo(description="", type=kind, outcome=outcome, cost=1.0)
+    third = max(1, n_ports // 3)
+    nodes = {
+        "a": m.NodeInfo(services=[], value=0, agent_installed=True, properties=["X"], firewall=fw(), vulnerabilities={
+            "find": vuln(m.VulnerabilityType.LOCAL, m.LeakedNodesId(["b", "c", "d"])),
+            "keys": vuln(m.VulnerabilityType.LOCAL, m.LeakedCredentials([m.CachedCredential("b", ports[0], "k0"), m.CachedCredential("c", ports[third], "k1"),
+                                                                         m.CachedCredential("d", ports[-1], "k2")]))}),
+        "b": m.NodeInfo(services=[m.ListeningService(p, allowedCredentials=["k0"]) for p in ports[:third]], value=10, properties=["Y"], firewall=fw(),
+                        vulnerabilities={"scan": vuln(m.VulnerabilityType.REMOTE, m.LeakedNodesId(["e"])),
+                                         "more": vuln(m.VulnerabilityType.LOCAL, m.LeakedCredentials([m.CachedCredential("e", ports[1], "k3")]))}),
+        "c": m.NodeInfo(services=[m.ListeningService(p, allowedCredentials=["k1"]) for p in ports[third:2 * third]], value=20, properties=["X", "Y"], firewall=fw()),
+        "d": m.NodeInfo(services=[m.ListeningService(p, allowedCredentials=["k2"]) for p in ports[2 * third:]], value=30, firewall=fw()),
+        "e": m.NodeInfo(services=[m.ListeningService(ports[1], allowedCredentials=["k3"])], value=50, properties=["Y"], firewall=fw()),
+    }
+    ids = m.Identifiers(properties=["X", "Y"], ports=ports, local_vulnerabilities=["find", "keys", "more"], remote_vulnerabilities=["scan"])
+    return m.Environment(network=m.create_network(nodes), vulnerability_library={}, identifiers=ids)
+
+
+@pytest.mark.parametrize("n_ports,cmax", [(15, 13), (15, 15), (15, 16), (13, 15), (9, 7)])
+def test_observation_with_many_ports_at_the_lds_budget(n_ports, cmax, monkeypatch):
+    """The per-source block of the connect mask (maximum_node_count * ports * maximum_total_credentials bytes, four variants in LDS per
+    wavefront) is used up to what a workgroup's LDS holds next to the staging areas (mcbs_api.hip blk_cap): 15 ports x 13 credentials x
+    16 nodes = 3 120 bytes fits (57 KB of LDS per workgroup), 15 x 15 x 16 = 3 600 does not and takes the period writer, 15 x 16 rows are
+    whole 16-byte chunks.  Every field and the flat Discrete mask against the oracle, both observation kernels."""
+    from marlon_amd import flatten as F
+    from marlon_amd._abi import RNG_PHILOX, EnvSpec
+    from oracle.oracle import Oracle
+    topo = F.flatten(_many_ports_environment(n_ports))
+    E = 131
+    spec = EnvSpec(n_envs=E, maximum_node_count=16, maximum_total_credentials=cmax, maximum_discoverable_credentials_per_action=5,
+                   attacker_goal=dict(own_atleast_percent=1.0), auto_reset=True, max_episode_steps=25, rng_kind=RNG_PHILOX, seed=3)
+    monkeypatch.setenv("MCBS_QUAD_OBS", "1")
+    quad = _engine().BatchEngine(topo, spec)
+    monkeypatch.delenv("MCBS_QUAD_OBS")
+    monkeypatch.setenv("MCBS_NO_QUAD_OBS", "1")
+    wave = _engine().BatchEngine(topo, spec)
+    monkeypatch.delenv("MCBS_NO_QUAD_OBS")
+    orc = Oracle(topo, spec)
+    fields = [f for f in parity.OBS_FIELDS]
+    connects = 0
+    for t in range(40):
+        a = quad.sample_actions(t % 5 != 4, seed=9, step=t)
+        oq, ow = quad.alloc_obs(fields + ["mask_discrete"]), wave.alloc_obs(fields + ["mask_discrete"])
+        quad.step_observe(a, oq)
+        wave.step_observe(a, ow)
+        oo = orc.alloc_obs(fields)
+        orc.step(a.cpu().numpy(), obs=oo)
+        connects += int(oo["mask_connect"].sum())
+        disc = np.concatenate([oo["mask_connect"].reshape(E, -1), oo["mask_local"].reshape(E, -1), oo["mask_remote"].reshape(E, -1)], axis=1)
+        for name, o in (("four envs per wavefront", oq), ("wavefront per env", ow)):
+            for f in fields:
+                np.testing.assert_array_equal(o[f].cpu().numpy(), oo[f], err_msg=f"{n_ports} ports x {cmax} step {t} {f} ({name})")
+            np.testing.assert_array_equal(o["mask_discrete"].cpu().numpy(), disc, err_msg=f"{n_ports} ports x {cmax} step {t} mask_discrete ({name})")
+    assert connects > 1000
+    quad.close()
+    wave.close()
+
+
 @pytest.mark.parametrize("n_nodes,seed", [(3, 1), (9, 2), (16, 3), (17, 4), (33, 5), (64, 6), (65, 7), (96, 11), (128, 8), (129, 9), (200, 10), (255, 12)])
 def test_random_topologies_engine_vs_oracle(n_nodes, seed):
     """The config-5 generator at sizes on both sides of every layout boundary (packed / general at 16 nodes, 1 / 2 / 4 words
