@@ -500,7 +500,8 @@ typedef struct mcbs_defender_wrapper_cfg {
 int  mcbs_defender_wrapper_post(mcbs_batch*, const mcbs_defender_wrapper_buffers* w, const mcbs_defender_wrapper_cfg* cfg, void* stream);
 /* One whole step of marlon's DefenderEnvWrapper for the batch (defend_wrapper.py:197-327): mcbs_defender_step and mcbs_defender_wrapper_post
  * in ONE launch — the shaping takes the turn's results from registers; w->valid / availability / evicted (the `in` members) are written
- * by this call — followed by the observation launch when obs is given. */
+ * by this call.  When obs is given the observation is written by the same launch (topologies of up to 32 nodes, arrays on 16-byte
+ * boundaries) or by a second one. */
 int  mcbs_defender_wrapper_step(mcbs_batch*, const int64_t* actions, const mcbs_defender_obs* obs, const mcbs_defender_wrapper_buffers* w,
                                 const mcbs_defender_wrapper_cfg* cfg, void* stream);
 

@@ -79,6 +79,7 @@ struct mcbs_batch {
     uint32_t* ere_lists_dev = nullptr;
     // developer switches, read ONCE at batch creation (getenv on every launch costs more than the launch itself)
     bool lds_topo = false, no_fused_masks = false, slow_masks = false, no_row_masks = false;
+    bool no_fused_defender_obs = false;   // MCBS_NO_FUSED_DEFENDER_OBS=1: the learned defender's observation as a launch of its own
     bool no_quad_obs = false;       // MCBS_NO_QUAD_OBS=1: a wavefront per env for small topologies' observations with mask fields (rounds 1-2)
     bool force_quad_obs = false;    // MCBS_QUAD_OBS=1: obs_quad_kernel also where mask rows are whole cache lines
     bool no_block_masks = false;    // MCBS_NO_BLOCK_MASKS=1: round 2's fused mask writers (rows switched on / off per chunk)
@@ -330,7 +331,7 @@ extern "C" int mcbs_batch_create(const mcbs_topology* topo, const mcbs_batch_cfg
     b->lds_topo = getenv("MCBS_LDS_TOPO") != nullptr; b->no_fused_masks = getenv("MCBS_NO_FUSED_MASKS") != nullptr;
     b->slow_masks = getenv("MCBS_SLOW_MASKS") != nullptr; b->no_row_masks = getenv("MCBS_NO_ROW_MASKS") != nullptr;
     b->no_fused_wrapper = getenv("MCBS_NO_FUSED_WRAPPER") != nullptr; b->no_block_masks = getenv("MCBS_NO_BLOCK_MASKS") != nullptr;
-    b->no_quad_obs = getenv("MCBS_NO_QUAD_OBS") != nullptr; b->force_quad_obs = getenv("MCBS_QUAD_OBS") != nullptr;
+    b->no_quad_obs = getenv("MCBS_NO_QUAD_OBS") != nullptr; b->no_fused_defender_obs = getenv("MCBS_NO_FUSED_DEFENDER_OBS") != nullptr; b->force_quad_obs = getenv("MCBS_QUAD_OBS") != nullptr;
     if (const char* ov = getenv("MCBS_STEP_BLOCK")) b->step_block_override = (uint32_t)atoi(ov);   // experiments only (64, 128 or 256)
     const uint32_t E = cfg->n_envs, N = h->n_nodes;
     DevState& S = b->S;
@@ -1224,6 +1225,22 @@ extern "C" int mcbs_mask_logits(mcbs_batch* b, void* logits, int32_t dtype, size
 }
 
 // ------------------------------------------------------------------ learned defender
+// The observation written by the turn kernel's own workgroups (one launch per turn): topologies of up to 32 nodes and 256 services,
+// output arrays on 16-byte boundaries (the 128 envs of a workgroup are one contiguous region of each array, stored as 16-byte vectors).
+// MCBS_NO_FUSED_DEFENDER_OBS=1: the separate launch.
+static DefObs fused_defender_obs(const mcbs_batch* b, const mcbs_defender_obs* o) {
+    DefObs d{};
+    if (!o) return d;
+    d.infected = o->infected_nodes; d.fw_in = o->incoming_firewall_status; d.fw_out = o->outgoing_firewall_status; d.services = o->services_status;
+    d.n_services = b->C.n_services;
+    const uint32_t N = b->S.N ? b->S.N : 1u;
+    d.dN = fast_div_host(N); d.d6N = fast_div_host(6u * N); d.dS = fast_div_host(d.n_services ? d.n_services : 1u);
+    auto al = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
+    const bool aligned = al(d.infected) && al(d.fw_in) && al(d.fw_out) && al(d.services);
+    d.fused = (b->S.N <= 32u && d.n_services <= 256u && aligned && !b->no_fused_defender_obs) ? 1u : 0u;
+    return d;
+}
+
 static int launch_defender_obs(mcbs_batch* b, const mcbs_defender_obs* o, hipStream_t st) {
     const uint32_t total = b->S.E * b->S.N;
     hipLaunchKernelGGL(defender_obs_kernel, dim3((total + 255) / 256), dim3(256), 0, st, b->S, b->T, o->infected_nodes,
@@ -1239,11 +1256,12 @@ extern "C" int mcbs_defender_step(mcbs_batch* b, const int64_t* actions, uint8_t
     hipStream_t st = (hipStream_t)stream;
     b->all_fresh = false;
     const dim3 grid((b->S.E + 127) / 128), block(128);
-    if (b->S.WT == 1) hipLaunchKernelGGL((defender_kernel<1>), grid, block, 0, st, b->S, b->T, b->C_dev, actions, valid, availability, evicted);
-    else if (b->S.WT == 2) hipLaunchKernelGGL((defender_kernel<2>), grid, block, 0, st, b->S, b->T, b->C_dev, actions, valid, availability, evicted);
-    else hipLaunchKernelGGL((defender_kernel<4>), grid, block, 0, st, b->S, b->T, b->C_dev, actions, valid, availability, evicted);
+    const DefObs dob = fused_defender_obs(b, obs);
+    if (b->S.WT == 1) hipLaunchKernelGGL((defender_kernel<1>), grid, block, 0, st, b->S, b->T, b->C_dev, actions, valid, availability, evicted, dob);
+    else if (b->S.WT == 2) hipLaunchKernelGGL((defender_kernel<2>), grid, block, 0, st, b->S, b->T, b->C_dev, actions, valid, availability, evicted, dob);
+    else hipLaunchKernelGGL((defender_kernel<4>), grid, block, 0, st, b->S, b->T, b->C_dev, actions, valid, availability, evicted, dob);
     int rc = launch_ok("defender step");
-    if (rc || !obs) return rc;
+    if (rc || !obs || dob.fused) return rc;
     return launch_defender_obs(b, obs, st);
 }
 
@@ -1257,11 +1275,12 @@ extern "C" int mcbs_defender_wrapper_step(mcbs_batch* b, const int64_t* actions,
     hipStream_t st = (hipStream_t)stream;
     b->all_fresh = false;
     const dim3 grid((b->S.E + 127) / 128), block(128);
-    if (b->S.WT == 1) hipLaunchKernelGGL((defender_turn_post_kernel<1>), grid, block, 0, st, b->S, b->T, b->C_dev, actions, *w, *cfg);
-    else if (b->S.WT == 2) hipLaunchKernelGGL((defender_turn_post_kernel<2>), grid, block, 0, st, b->S, b->T, b->C_dev, actions, *w, *cfg);
-    else hipLaunchKernelGGL((defender_turn_post_kernel<4>), grid, block, 0, st, b->S, b->T, b->C_dev, actions, *w, *cfg);
+    const DefObs dob = fused_defender_obs(b, obs);
+    if (b->S.WT == 1) hipLaunchKernelGGL((defender_turn_post_kernel<1>), grid, block, 0, st, b->S, b->T, b->C_dev, actions, *w, *cfg, dob);
+    else if (b->S.WT == 2) hipLaunchKernelGGL((defender_turn_post_kernel<2>), grid, block, 0, st, b->S, b->T, b->C_dev, actions, *w, *cfg, dob);
+    else hipLaunchKernelGGL((defender_turn_post_kernel<4>), grid, block, 0, st, b->S, b->T, b->C_dev, actions, *w, *cfg, dob);
     int rc = launch_ok("defender turn + reward shaping");
-    if (rc || !obs) return rc;
+    if (rc || !obs || dob.fused) return rc;
     return launch_defender_obs(b, obs, st);
 }
 

@@ -4,7 +4,8 @@
 //                         then LearningDefender.executeAction (marlon/defender_agents/defender.py:31-107):
 //                         DefenderAgentActions.on_attacker_step_taken (actions.py:714-746) and, if valid, the action.
 //                         One lane per env; shares the re-imaging ring, the availability code and reimage() with the step kernel.
-//   defender_obs_kernel : DefenderEnvWrapper.observe (defend_wrapper.py:492-534), one thread per (env, node).
+//   defender_obs_kernel : DefenderEnvWrapper.observe (defend_wrapper.py:492-534), one thread per (env, node); for topologies of up to
+//                         32 nodes the turn kernels write it themselves (defender_observe_env), one launch per turn.
 // Firewall rule LISTS are state objects of their own (several nodes / directions may hold the same Python list, and
 // copy.deepcopy keeps that aliasing): per (env, list) 12 bits — for each of the six names the learned defender can name
 // (RDP, SSH, HTTPS, HTTP, su, sudo) "a rule with that name exists" and "the first such rule is ALLOW".  That is everything
@@ -98,17 +99,123 @@ __device__ __forceinline__ void defender_turn(const DevState& S, const Topo& T, 
     evicted_out = C.defender_goal_eviction && ln.owned == 0;          // __defender_goal_reached (env.py:1112-1116)
 }
 
+// DefenderEnvWrapper.observe (defend_wrapper.py:492-534) written by the TURN kernel's own workgroup, for topologies of up to 32 nodes: the
+// separate observation launch (a thread per (env, node), three dependent loads, 13 byte stores) took as long as the turn itself (6.5 of
+// the 12 us of a DefenderVecEnv.step at 16 384 ToyCtf envs).  Each lane parks its env's bits in LDS after its turn (agent-installed word;
+// per node the six rule-name bits of the incoming and the outgoing list, read back from its own stores), and the workgroup's 128 envs —
+// one contiguous region of each output array — leave as 16-byte stores, thread by thread.  (A first version that had every lane store
+// its own env's ~80 bytes / shorts was SLOWER than the extra launch: 14.4 against 12.2 us — 64 scattered partial lines per instruction.)
+struct DefObs {
+    int8_t* infected; int8_t* fw_in; int8_t* fw_out; int8_t* services;
+    uint32_t n_services, fused;
+    FastDiv dN, d6N, dS;                 // divisors: nodes, six bytes per node, services
+};
+constexpr uint32_t DEF_WG = 128u, DEF_NMAX = 32u, DEF_SMAX = 256u;
+struct DefStage { uint32_t inst[DEF_WG]; uint16_t fw[DEF_WG * DEF_NMAX]; uint8_t svc[DEF_SMAX]; };      // 8.9 KB per workgroup
+
+template <int WT>
+__device__ __forceinline__ void defender_observe_wg(const DevState& S, const Topo& T, const DefObs& o, const uint32_t e, const bool valid, DefStage& st) {
+    const uint32_t tid = threadIdx.x, N = S.N, e0 = blockIdx.x * DEF_WG;
+    const uint32_t n_env = S.E - e0 < DEF_WG ? S.E - e0 : DEF_WG;
+    if (valid) {
+        const uint8_t* body = S.body + (size_t)e * S.body_stride;
+        const uint16_t* fw = reinterpret_cast<const uint16_t*>(body + S.off_fw);
+        const mcbs_node_static* NS = reinterpret_cast<const mcbs_node_static*>(T.base + T.H().off_node);
+        st.inst[tid] = (uint32_t)S.get(M_INST, 0u, e);                   // N <= 32: the low bits of word 0
+        for (uint32_t n = 0; n < N; ++n) {                               // (uniform: node statics through the scalar cache)
+            const uint32_t lists = NS[n].fw_lists;
+            st.fw[tid * DEF_NMAX + n] = (uint16_t)((fw[lists & 0xFFFFu] & 63u) | ((fw[lists >> 16] & 63u) << 8));
+        }
+    }
+    if (o.services) {                                                    // services never change state (see below): the initial flags
+        const mcbs_service* sv = reinterpret_cast<const mcbs_service*>(T.base + T.H().off_service);
+        for (uint32_t k = tid; k < o.n_services; k += DEF_WG) st.svc[k] = sv[k].running ? 1 : 0;
+    }
+    __syncthreads();
+    // byte j of a 16-byte chunk held in four dwords
+#define MCBS_PUT_BYTE(w, j, v) w[(j) >> 2] |= (uint32_t)(v) << (8u * ((j) & 3u))
+    if (o.infected) {
+        int8_t* p = o.infected + (size_t)e0 * N;
+        const uint32_t R = n_env * N;
+        for (uint32_t b0 = tid * 16u; b0 < R; b0 += DEF_WG * 16u) {
+            uint32_t env = fdiv(b0, o.dN), node = b0 - env * N, bits = st.inst[env], w[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (uint32_t j = 0; j < 16u; ++j) {
+                MCBS_PUT_BYTE(w, j, (bits >> node) & 1u);
+                if (++node == N) { node = 0; env = env + 1u < DEF_WG ? env + 1u : env; bits = st.inst[env]; }
+            }
+            if (b0 + 16u <= R) *reinterpret_cast<uint4*>(p + b0) = make_uint4(w[0], w[1], w[2], w[3]);
+            else {
+#pragma unroll
+                for (uint32_t j = 0; j < 16u; ++j)
+                    if (b0 + j < R) p[b0 + j] = (int8_t)((w[j >> 2] >> (8u * (j & 3u))) & 0xFFu);
+            }
+        }
+    }
+    auto stream_fw = [&](int8_t* dst, const uint32_t shift) {            // six 0 / 1 bytes per (env, node): two per step (6 is even)
+        int8_t* p = dst + (size_t)e0 * 6u * N;
+        const uint32_t R = n_env * 6u * N;
+        for (uint32_t b0 = tid * 16u; b0 < R; b0 += DEF_WG * 16u) {
+            uint32_t env = fdiv(b0, o.d6N);
+            const uint32_t rem = b0 - env * 6u * N;
+            uint32_t node = rem / 6u, k = rem - node * 6u, f = (uint32_t)st.fw[env * DEF_NMAX + node] >> shift, w[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (uint32_t j = 0; j < 16u; j += 2u) {
+                MCBS_PUT_BYTE(w, j, (f >> k) & 1u);
+                MCBS_PUT_BYTE(w, j + 1u, (f >> (k + 1u)) & 1u);
+                k += 2u;
+                if (k == 6u) {
+                    k = 0;
+                    if (++node == N) { node = 0; env = env + 1u < DEF_WG ? env + 1u : env; }
+                    f = (uint32_t)st.fw[env * DEF_NMAX + node] >> shift;
+                }
+            }
+            if (b0 + 16u <= R) *reinterpret_cast<uint4*>(p + b0) = make_uint4(w[0], w[1], w[2], w[3]);
+            else {
+#pragma unroll
+                for (uint32_t j = 0; j < 16u; j += 2u)
+                    if (b0 + j < R) *reinterpret_cast<uint16_t*>(p + b0 + j) = (uint16_t)((w[j >> 2] >> (8u * (j & 3u))) & 0xFFFFu);
+            }
+        }
+    };
+    if (o.fw_in) stream_fw(o.fw_in, 0u);
+    if (o.fw_out) stream_fw(o.fw_out, 8u);
+    if (o.services && o.n_services) {
+        const uint32_t Sv = o.n_services, R = n_env * Sv;
+        int8_t* p = o.services + (size_t)e0 * Sv;
+        for (uint32_t b0 = tid * 16u; b0 < R; b0 += DEF_WG * 16u) {
+            uint32_t k = b0 - fdiv(b0, o.dS) * Sv, w[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (uint32_t j = 0; j < 16u; ++j) {
+                MCBS_PUT_BYTE(w, j, st.svc[k]);
+                if (++k == Sv) k = 0;
+            }
+            if (b0 + 16u <= R) *reinterpret_cast<uint4*>(p + b0) = make_uint4(w[0], w[1], w[2], w[3]);
+            else {
+#pragma unroll
+                for (uint32_t j = 0; j < 16u; ++j)
+                    if (b0 + j < R) p[b0 + j] = (int8_t)((w[j >> 2] >> (8u * (j & 3u))) & 0xFFu);
+            }
+        }
+    }
+#undef MCBS_PUT_BYTE
+}
+
 template <int WT>
 __global__ __launch_bounds__(128) void defender_kernel(DevState S, Topo T, const StepCfg* __restrict__ Cp, const int64_t* actions,
-                                                       uint8_t* valid_out, double* avail_out, uint8_t* evicted_out) {
+                                                       uint8_t* valid_out, double* avail_out, uint8_t* evicted_out, DefObs obs) {
+    __shared__ DefStage stage;
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= S.E) return;
-    bool ok, evicted;
-    double avail;
-    defender_turn<WT>(S, T, *Cp, actions, e, ok, avail, evicted);
-    if (valid_out) valid_out[e] = ok ? 1 : 0;
-    if (avail_out) avail_out[e] = avail;
-    if (evicted_out) evicted_out[e] = evicted ? 1 : 0;
+    const bool valid = e < S.E;
+    if (valid) {
+        bool ok, evicted;
+        double avail;
+        defender_turn<WT>(S, T, *Cp, actions, e, ok, avail, evicted);
+        if (valid_out) valid_out[e] = ok ? 1 : 0;
+        if (avail_out) avail_out[e] = avail;
+        if (evicted_out) evicted_out[e] = evicted ? 1 : 0;
+    }
+    if (obs.fused) defender_observe_wg<WT>(S, T, obs, e, valid, stage);        // (uniform: the whole workgroup)
 }
 
 // DefenderEnvWrapper.step's reward shaping (defend_wrapper.py:228-282) for one env, from the turn's results (in registers or loaded)
@@ -147,16 +254,20 @@ __global__ __launch_bounds__(256) void defender_wrapper_post_kernel(uint32_t E, 
 // from registers; valid / availability / evicted are still written for the caller)
 template <int WT>
 __global__ __launch_bounds__(128) void defender_turn_post_kernel(DevState S, Topo T, const StepCfg* __restrict__ Cp, const int64_t* actions,
-                                                                 mcbs_defender_wrapper_buffers w, mcbs_defender_wrapper_cfg c) {
+                                                                 mcbs_defender_wrapper_buffers w, mcbs_defender_wrapper_cfg c, DefObs obs) {
+    __shared__ DefStage stage;
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= S.E) return;
-    bool ok, evicted;
-    double avail;
-    defender_turn<WT>(S, T, *Cp, actions, e, ok, avail, evicted);
-    const_cast<uint8_t*>(w.valid)[e] = ok ? 1 : 0;
-    const_cast<double*>(w.availability)[e] = avail;
-    const_cast<uint8_t*>(w.evicted)[e] = evicted ? 1 : 0;
-    defender_shape(w, c, e, ok, avail, evicted);
+    const bool valid = e < S.E;
+    if (valid) {
+        bool ok, evicted;
+        double avail;
+        defender_turn<WT>(S, T, *Cp, actions, e, ok, avail, evicted);
+        const_cast<uint8_t*>(w.valid)[e] = ok ? 1 : 0;
+        const_cast<double*>(w.availability)[e] = avail;
+        const_cast<uint8_t*>(w.evicted)[e] = evicted ? 1 : 0;
+        defender_shape(w, c, e, ok, avail, evicted);
+    }
+    if (obs.fused) defender_observe_wg<WT>(S, T, obs, e, valid, stage);        // (uniform: the whole workgroup)
 }
 
 __global__ __launch_bounds__(256) void defender_obs_kernel(DevState S, Topo T, int8_t* infected, int8_t* fw_in, int8_t* fw_out,

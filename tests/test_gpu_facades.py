@@ -268,20 +268,37 @@ def test_defender_vec_env_matches_marlon_defender_wrapper(name):
     att.close()
 
 
-def test_defender_step_batch_against_oracle():
-    """2 048 ToyCtf envs, random attacker rows and random defender vectors: validity, availability bits, eviction, the four
-    observation fields and the attacker's rewards equal the oracle's (which keeps real rule lists) at every step."""
+@pytest.mark.parametrize("case", ["toyctf", "toyctf_separate_observation", "random24", "random70"])
+def test_defender_step_batch_against_oracle(case, monkeypatch):
+    """Random attacker rows and random defender vectors on a batch that does not fill its last workgroup: validity, availability bits,
+    eviction, the four observation fields and the attacker's rewards equal the oracle's (which keeps real rule lists) at every step.
+    ToyCtf and a 24-node instance of the config-5 generator write the observation from the turn kernel itself (round 3: one launch per
+    turn), MCBS_NO_FUSED_DEFENDER_OBS=1 and the 70-node instance (two words per node set) through the separate observation launch;
+    buffers pre-filled with a sentinel.  defend_wrapper.py:329-412,492-534, defender.py:31-107."""
+    from marlon_amd import flatten as F, model
     from marlon_amd._abi import EnvSpec
+    from marlon_amd.samples import random_net
     from oracle.oracle import Oracle
-    topo = parity.topology_for("toyctf")
-    E, T = 2048, 120
-    spec = EnvSpec(n_envs=E, maximum_node_count=12, maximum_total_credentials=10, attacker_goal=dict(own_atleast=6, own_atleast_percent=1.0),
+    if case.startswith("toyctf"):
+        topo, nm, cm, E, T = parity.topology_for("toyctf"), 12, 10, 2048 + 37, 120
+    else:
+        n = int(case[6:])
+        topo = F.flatten(random_net.build(model, n, 5))
+        nm, cm, E, T = n, max(1, len(topo.triples)), 300 + 37, 60
+    spec = EnvSpec(n_envs=E, maximum_node_count=nm, maximum_total_credentials=cm, maximum_discoverable_credentials_per_action=8,
+                   attacker_goal=dict(own_atleast=6, own_atleast_percent=1.0),
                    maintain_sla=0.6, losing_reward=-5000.0, defender=("external",), auto_reset=True, max_episode_steps=80, seed=4)
+    if case == "toyctf_separate_observation":
+        monkeypatch.setenv("MCBS_NO_FUSED_DEFENDER_OBS", "1")
     eng = _engine_mod().BatchEngine(topo, spec)
+    monkeypatch.delenv("MCBS_NO_FUSED_DEFENDER_OBS", raising=False)
     orc = Oracle(topo, spec)
     rng = np.random.Generator(np.random.PCG64(9))
-    nvec = np.array([5, 10, 10, 6, 2, 10, 6, 2, 10, 3, 10, 3])
+    N = int(topo.n_nodes)
+    nvec = np.array([5, N, N, 6, 2, N, 6, 2, N, 3, N, 3])
     dobs = eng.alloc_defender_obs()
+    for v in dobs.values():
+        v.fill_(9)
     for t in range(T):
         a = eng.sample_actions(t % 4 != 0, seed=2, step=t)
         r, d = eng.step(a)
