@@ -143,6 +143,7 @@ class BatchEngine:
         self._shapes = obs_field_shapes(topo, spec)
         self.mask_discrete_stride = 0
         self._tape = None
+        self._raw_stream = None
         f32, u8, f64, i32 = torch.float32, torch.uint8, torch.float64, torch.int32
         dev = self.device
         self.reward = torch.zeros(self.E, dtype=f32, device=dev)
@@ -171,7 +172,14 @@ class BatchEngine:
 
     # -- helpers --
     def _stream(self) -> int:
-        return self.torch.cuda.current_stream(self.device).cuda_stream
+        """The raw handle of torch's current stream on this engine's device (queried per call: the caller may switch streams)."""
+        raw = self._raw_stream
+        if raw is None:
+            # torch's C binding answers in ~0.2 us; the Python-level current_stream() builds a Stream object first (~1.5 us of a ~10 us call)
+            get = getattr(self.torch._C, "_cuda_getCurrentRawStream", None)
+            idx = self.device.index if self.device.index is not None else self.torch.cuda.current_device()
+            raw = self._raw_stream = (lambda: get(idx)) if get is not None else (lambda: self.torch.cuda.current_stream(self.device).cuda_stream)
+        return raw()
 
     def alloc_obs(self, fields: Optional[Iterable[str]] = None) -> dict:
         t = self.torch
@@ -314,6 +322,32 @@ class BatchEngine:
                                                              C.byref(self._info_struct), C.byref(obs_struct), C.byref(bufs), float(modifier),
                                                              int(max_timesteps), int(bool(auto_reset)), C.byref(keep), C.byref(fresh), self._stream()),
                "mcbs_attacker_wrapper_step")
+
+    def wrapper_step_call(self, discrete: bool, decoded, obs_struct, bufs, modifier: float, max_timesteps: int, auto_reset: bool, keep, fresh):
+        """callable(actions_ptr): wrapper_step with every argument but the actions (and the stream, queried per call) bound ONCE — the
+        argument blocks' references and conversions are most of what a per-step call costs on the host next to the launch itself."""
+        fn, eng, lib, stream = self.lib.mcbs_attacker_wrapper_step, self, self.lib, self._stream       # (eng._h is None once closed: refused)
+        refs = (C.byref(self._info_struct), C.byref(obs_struct), C.byref(bufs), C.byref(keep), C.byref(fresh))
+        rows, mod, mt, ar = decoded.data_ptr(), float(modifier), int(max_timesteps), int(bool(auto_reset))
+        alive = (decoded, obs_struct, bufs, keep, fresh, self._info_struct)       # the blocks the references point into
+
+        def call(p: int, _alive=alive) -> None:
+            rc = fn(eng._h, None if discrete else p, p if discrete else None, rows, refs[0], refs[1], refs[2], mod, mt, ar, refs[3], refs[4], stream())
+            if rc:
+                _check(lib, rc, "mcbs_attacker_wrapper_step")
+        return call
+
+    def defender_wrapper_step_call(self, obs_struct, bufs, cfg):
+        """callable(actions_ptr): defender_wrapper_step with the argument blocks bound once."""
+        fn, eng, lib, stream = self.lib.mcbs_defender_wrapper_step, self, self.lib, self._stream
+        refs = (C.byref(obs_struct) if obs_struct is not None else None, C.byref(bufs), C.byref(cfg))
+        alive = (obs_struct, bufs, cfg)
+
+        def call(p: int, _alive=alive) -> None:
+            rc = fn(eng._h, p, refs[0], refs[1], refs[2], stream())
+            if rc:
+                _check(lib, rc, "mcbs_defender_wrapper_step")
+        return call
 
     def wrapper_step_launches(self, with_masks: bool) -> int:
         """Kernel launches per mcbs_attacker_wrapper_step of this batch (1: the whole wrapper step is one launch; 3 otherwise)."""

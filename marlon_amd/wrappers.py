@@ -95,6 +95,9 @@ class AttackerVecEnv:
         self._len_out = t.zeros(n_envs, dtype=t.int32, device=dev)
         self._n_done = t.zeros(1, dtype=t.int32, device=dev)
         self._wb = self._keep = self._fresh = self._reset_rows = None
+        self._calls = {}                                   # bound library calls (engine.wrapper_step_call), one per output set and settings
+        self._dev_index = self.engine.device.index if self.engine.device.index is not None else t.cuda.current_device()
+        self._action_shape = (n_envs,) if self.discrete else (n_envs, 10)
         self._obs_views = self._terminal_views = None
         self._ring, self._slot = None, 0
         self._one_launch = None
@@ -180,10 +183,12 @@ class AttackerVecEnv:
         (:350-352), episode returns and what DummyVecEnv.step_wait does for an env that reports done: keep its last observation, reset
         it, return the reset observation (every env resets to the same state, so that is row 0 of reset()'s observation)."""
         t = self.torch
-        a = actions if isinstance(actions, t.Tensor) else t.as_tensor(np.asarray(actions))
-        a = a.to(device=self.engine.device, dtype=t.int64).contiguous()
-        want = (self.num_envs,) if self.discrete else (self.num_envs, 10)
-        if tuple(a.shape) != want:
+        a = actions
+        if not (type(a) is t.Tensor and a.dtype is t.int64 and a.is_cuda and a.get_device() == self._dev_index and a.is_contiguous()):
+            a = a if isinstance(a, t.Tensor) else t.as_tensor(np.asarray(a))       # (the common case — the policy's own int64 tensor — skips this)
+            a = a.to(device=self.engine.device, dtype=t.int64).contiguous()
+        want = self._action_shape
+        if a.shape != want:
             raise ValueError(f"expected actions of shape {want}, got {tuple(a.shape)}")
         if self._keep is None:
             eng = self.engine
@@ -193,8 +198,13 @@ class AttackerVecEnv:
         if self._wb is None:
             self._wb = self._wrapper_buffers(self._invalid, self.engine.terminated if self.use_graph else self._terminated_out, self._rewards,
                                              self._truncated, self._ret_out, self._len_out, self._executed)
-        self.engine.wrapper_step(a, self.discrete, self._rows, self._obs_block, self._wb, self.invalid_action_reward_modifier, self.max_timesteps,
-                                 self.auto_reset, self._keep, self._fresh)
+        # the library call with every argument block bound once per (output set, wrapper settings): engine.wrapper_step_call
+        key = (id(self._wb), self.invalid_action_reward_modifier, self.max_timesteps, self.auto_reset)
+        call = self._calls.get(key)
+        if call is None:
+            call = self._calls[key] = self.engine.wrapper_step_call(self.discrete, self._rows, self._obs_block, self._wb, self.invalid_action_reward_modifier,
+                                                                    self.max_timesteps, self.auto_reset, self._keep, self._fresh)
+        call(a.data_ptr())
 
     def _wrapper_buffers(self, invalid, terminated, rewards, truncated, ret_out, len_out, executed):
         from ._abi import WrapperBuffers
@@ -352,14 +362,16 @@ class DefenderVecEnv:
                     o["truncated"], o["breached"], o["won"])])
                 info = {"valid_action": o["valid"].view(t.bool), "network_availability": o["availability"], "sla_breached": o["breached"].view(t.bool),
                         "defender_won": o["won"].view(t.bool)}
-                self._ring.append((o, wb, info))
+                self._ring.append((o, wb, info, self.engine.defender_wrapper_step_call(self._obs_block, wb, self._wc)))
         if not self.use_graph:
             self._slot ^= 1
-        o, wb, info = self._ring[self._slot]
-        a = actions if isinstance(actions, t.Tensor) else t.as_tensor(np.asarray(actions))
-        a = a.to(device=dev, dtype=t.int64).contiguous()
-        if tuple(a.shape) != (E, 12):
+        o, wb, info, call = self._ring[self._slot]
+        a = actions
+        if not (type(a) is t.Tensor and a.dtype is t.int64 and a.is_cuda and a.get_device() == self.attacker._dev_index and a.is_contiguous()):
+            a = a if isinstance(a, t.Tensor) else t.as_tensor(np.asarray(a))
+            a = a.to(device=dev, dtype=t.int64).contiguous()
+        if a.shape != (E, 12):
             raise ValueError(f"defender actions must have shape ({E}, 12), got {tuple(a.shape)}")
-        self.engine.defender_wrapper_step(a, self._obs_block, wb, self._wc)
+        call(a.data_ptr())
         self._out = o
         return self._obs, o["reward"], o["terminated"], o["truncated"], dict(info)
