@@ -48,6 +48,13 @@ def load_library(path: Optional[str] = None):
         raise NativeLibraryMissing(
             f"{p} not found: the HIP extension has not been built. Build it with `make -C marlon_amd/csrc` "
             f"(hipcc, gfx950). There is no CPU fallback for the step engine.")
+    # torch first: it ships its own HIP runtime (torch/lib/libamdhip64.so), and the first copy a process maps is the one every later
+    # library with that soname binds to.  Loaded before torch, libmcbs.so pulled in /opt/rocm's runtime and torch then ran on a runtime it
+    # was not built against ("no ROCm-capable device is detected" from the first allocation; build() followed by smoke() in one process).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(p)
     lib.mcbs_last_error.restype = C.c_char_p
     lib.mcbs_abi_version.restype = C.c_uint32
