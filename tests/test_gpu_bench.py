@@ -76,3 +76,10 @@ def test_bench_two_ranks_on_one_gpu():
     for x in cf:                                           # aggregate over both shards, from the MAX-over-ranks host clock
         assert abs(x["env_steps_per_s"] - 2 * x["envs_per_gpu"] / (x["ms_per_step_host_clock_max_over_ranks"] * 1e-3)) / x["env_steps_per_s"] < 1e-6
     assert b["headline_with_resets"]["episodes_ended"] > 0 and "observe" not in b and "extras_error" not in b
+
+
+def test_build_then_smoke_in_one_process():
+    """__graft_entry__.build() loads the library (ABI check) before anything imported torch; smoke() in the same process then runs on the
+    HIP runtime the library brought in — the wrong one unless load_library imports torch first ("no ROCm-capable device is detected")."""
+    out = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build(); g.smoke()"], cwd=REPO, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "smoke ok" in out.stdout, (out.stdout[-1500:], out.stderr[-1500:])

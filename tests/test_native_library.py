@@ -129,3 +129,15 @@ def test_every_launching_entry_point_selects_the_batch_device():
         assert g and g.start() < w.start(), f"{m.group(1)} touches the device before selecting the batch's device"
         checked += 1
     assert checked >= 25
+
+
+def test_library_is_loaded_after_torch():
+    """libmcbs.so and PyTorch-ROCm both need libamdhip64, and the copy a process maps first serves both: load_library must bring torch's
+    in before the library's own dependency resolves to /opt/rocm's (INTEGRATION.md "One HIP runtime per process").  Fresh interpreter."""
+    import subprocess
+    import sys
+    code = ("import sys; from marlon_amd import engine; assert 'torch' not in sys.modules, 'importing the package must stay light'; "
+            "engine.load_library(); assert 'torch' in sys.modules; print('ok')")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=repo, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
