@@ -349,9 +349,10 @@ def test_gym_facade_exposes_what_marlons_callers_read():
     env.close()
 
 
-@pytest.mark.parametrize("n_nodes,masks", [(24, True), (24, False), (70, True), (70, False)])
+@pytest.mark.parametrize("n_nodes,masks", [(12, True), (12, False), (16, False), (24, True), (24, False), (70, True), (70, False)])
 def test_attacker_vec_env_on_larger_topologies_against_oracle(n_nodes, masks):
-    """The batched attacker wrapper beyond the reference's sample topologies (the config-5 generator at 24 and 70 nodes: general state layout,
+    """The batched attacker wrapper beyond the reference's sample topologies (the config-5 generator at 12 / 16 nodes: general state layout
+    with the sixteen-lanes-per-env observation kernels and the three-launch step; at 24 and 70 nodes: general state layout,
     one and two words per set, action spaces too large for the fused mask writers, flat-mask rows padded to whole cache lines), with the
     oracle as checker of the wrapper's semantics: MultiDiscrete actions drawn on the host (a share of them with undiscovered node indices:
     intercepted), in-env ScanAndReimage, truncation and auto-reset — rewards, flags, interception, the small observation fields and (when
