@@ -666,3 +666,40 @@ def test_terminal_observation_of_an_intercepted_last_action_is_the_one_that_stan
         assert torch.equal(x[sel], standing[k][sel]), f"terminal observation {k} is not the observation that stood"
     for env in (ref, fused, three):
         env.close()
+
+
+def test_wrapper_steps_on_a_side_stream_equal_the_default_stream():
+    """Every library call is enqueued on torch's CURRENT stream of the batch's device, queried per call (engine._stream: torch's raw-stream
+    binding).  The same masked-random trajectory on the default stream and inside `torch.cuda.stream(side)` — actions produced and results
+    consumed on that same side stream, no synchronize in between — must agree step for step."""
+    import torch
+    from marlon_amd.samples import chainpattern
+    from marlon_amd.wrappers import AttackerVecEnv
+    E, T = 3000, 40
+    kw = dict(maximum_node_count=12, maximum_total_credentials=12, discrete=True, max_timesteps=17, materialize_masks=False)
+    a_env, b_env = AttackerVecEnv(chainpattern.new_environment(10), E, **kw), AttackerVecEnv(chainpattern.new_environment(10), E, **kw)
+    dev = a_env.engine.device
+    side = torch.cuda.Stream(device=dev)
+    assert a_env.engine._stream() == torch.cuda.current_stream(dev).cuda_stream
+    with torch.cuda.stream(side):
+        assert b_env.engine._stream() == side.cuda_stream != torch.cuda.default_stream(dev).cuda_stream
+    ga, gb = torch.Generator(device=dev).manual_seed(3), torch.Generator(device=dev).manual_seed(3)
+    ra, rb = [], []
+    for t in range(T):
+        la = torch.rand((E, a_env.discrete_n), generator=ga, device=dev)
+        acts = a_env.mask_logits(la, fill=-1.0).argmax(dim=1)
+        o, r, te, tr, info = a_env.step(acts)
+        ra.append((r.clone(), te.clone(), tr.clone(), o["discovered_node_count"].clone()))
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        for t in range(T):
+            lb = torch.rand((E, b_env.discrete_n), generator=gb, device=dev)
+            acts = b_env.mask_logits(lb, fill=-1.0).argmax(dim=1)
+            o, r, te, tr, info = b_env.step(acts)
+            rb.append((r.clone(), te.clone(), tr.clone(), o["discovered_node_count"].clone()))
+    side.synchronize()
+    for t, (x, y) in enumerate(zip(ra, rb)):
+        for u, v in zip(x, y):
+            assert torch.equal(u, v), f"step {t}: side stream differs from the default stream"
+    assert sum(int((x[1] | x[2]).sum()) for x in ra) > E
+    a_env.close(); b_env.close()
