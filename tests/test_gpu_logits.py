@@ -13,6 +13,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("trace", ["chain10_mix_s3", "toyctf_defender_s11", "random24_defender_s51"])
 def test_mask_logits_equals_where_oracle_mask(trace):
+    """fp32 and bf16 logits, dense rows, an offset view whose rows are neither 16-byte aligned nor a multiple of four long, and rows padded
+    to whole 16-byte groups plus two groups (row_stride > actions: the padding is not the mask's to write)."""
     import torch
     from marlon_amd import engine
     from marlon_amd._abi import RNG_PHILOX
@@ -59,6 +61,18 @@ def test_mask_logits_equals_where_oracle_mask(trace):
         eng.mask_logits(view, fill)
         np.testing.assert_array_equal(view.cpu().numpy(), ref, err_msg=f"{trace} step {t} unaligned rows")
         assert float(wide[:, 0].abs().sum()) == 0.0 and float(wide[:, A + 1:].abs().sum()) == 0.0      # nothing outside the rows was touched
+        # rows padded to a whole number of 16-byte groups (and two groups more): fp32 and bf16, padding untouched
+        for dt, pad_to in ((torch.float32, 4), (torch.bfloat16, 8)):
+            Ap = (A + pad_to - 1) // pad_to * pad_to + 2 * pad_to
+            widep = torch.full((E, Ap), 7.0, device=eng.device, dtype=dt)
+            vp = widep[:, :A]
+            src = logits.to(dt)
+            vp.copy_(src)
+            eng.mask_logits(vp, fill)
+            want = torch.where(torch.as_tensor(mask), src.cpu(), torch.tensor(fill, dtype=dt))
+            assert torch.equal(vp.cpu().view(torch.int16 if dt == torch.bfloat16 else torch.int32),
+                               want.view(torch.int16 if dt == torch.bfloat16 else torch.int32)), f"{trace} step {t} padded rows {dt}"
+            assert bool((widep[:, A:] == 7.0).all()), f"{trace} step {t} padded rows {dt}: padding written"
     assert mask.any() and not mask.all()
     eng.close()
 
